@@ -1,0 +1,170 @@
+"""ctypes binding of libadamdehaze_hip.so (the C ABI declared in include/adam_dehaze_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  torch is used only for device memory (data_ptr) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libadamdehaze_hip.so")
+_lib: Optional[C.CDLL] = None
+
+ACT_NONE, ACT_RELU = 0, 1
+
+i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """struct adh_conv_desc (include/adam_dehaze_hip.h)."""
+    _fields_ = [
+        ("in_", vp), ("out", vp), ("wp", vp), ("scale", vp), ("shift", vp), ("residual", vp), ("stats", vp),
+        ("N", i32), ("IH", i32), ("IW", i32), ("Cin", i32), ("in_cstride", i32),
+        ("OH", i32), ("OW", i32), ("Cout", i32), ("out_cstride", i32), ("res_cstride", i32),
+        ("VH", i32), ("VW", i32),
+        ("in_sy", i32), ("in_sx", i32),
+        ("out_sy", i32), ("out_sx", i32), ("out_oy", i32), ("out_ox", i32),
+        ("KH", i32), ("KW", i32),
+        ("dy0", i32), ("dx0", i32), ("dstep_y", i32), ("dstep_x", i32),
+        ("act", i32), ("NcP", i32),
+    ]
+
+
+class WLayout(C.Structure):
+    """struct adh_wlayout."""
+    _fields_ = [
+        ("K", i32), ("Nc", i32), ("KHt", i32), ("KWt", i32),
+        ("tap_off0", i32), ("tap_off_sy", i32), ("tap_off_sx", i32),
+        ("stride_k", i32), ("stride_n", i32),
+    ]
+
+
+PD = C.POINTER(ConvDesc)
+PL = C.POINTER(WLayout)
+
+# name -> argtypes (restype is always int)
+_SIGNATURES = {
+    "adh_version": [],
+    "adh_conv_lds_bytes": [PD],
+    "adh_conv_num_blocks": [PD],
+    "adh_pack_weights": [vp, vp, PL, vp],
+    "adh_conv_forward": [vp, PD],
+    "adh_conv_wgrad": [vp, PD, vp, i32],
+    "adh_wgrad_reduce": [vp, vp, i32, i32, i32, PL, vp, i32],
+    "adh_bn_finalize": [vp, vp, i32, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp],
+    "adh_bn_fold_eval": [vp, i32, vp, vp, vp, vp, f32, vp, vp, vp],
+    "adh_bn_apply": [vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, i64, i32],
+    "adh_bn_bwd_num_blocks": [i64, i32],
+    "adh_bn_bwd_reduce": [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32],
+    "adh_bn_bwd_finalize": [vp, vp, i32, i32, f64, vp, vp, vp, vp, i32, vp],
+    "adh_bn_bwd_apply": [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i64, i32],
+    "adh_cbam_pool": [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp],
+    "adh_cbam_pool_num_blocks": [i32],
+    "adh_cbam_mlp": [vp, vp, vp, vp, i32, i32, i32, vp, vp],
+    "adh_cbam_spatial_stats": [vp, vp, i32, vp, i32, i32, i32, vp, vp],
+    "adh_cbam_apply": [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32],
+    "adh_cbam_bwd_a": [vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, vp],
+    "adh_cbam_bwd_b": [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, i32],
+    "adh_cbam_bwd_b_num_blocks": [i32, i32, i32],
+    "adh_cbam_bwd_c": [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, i32],
+    "adh_cbam_bwd_d": [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32],
+    "adh_cbam_bwd_e": [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32],
+    "adh_image_to_nhwc8": [vp, vp, i32, i32, i32, vp],
+    "adh_nchw_to_nhwc": [vp, vp, i32, i32, i32, i32, vp, i32],
+    "adh_nhwc_to_nchw": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "adh_head_blend": [vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp],
+    "adh_head_blend_bwd": [vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, i32],
+    "adh_head_blend_bwd_num_blocks": [i32, i32, i32],
+    "adh_softmax3": [vp, vp, f32, i32, vp],
+    "adh_soft_blend": [vp, vp, vp, vp, vp, i32, i64, vp],
+    "adh_soft_blend_bwd": [vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, i32],
+    "adh_argmax3": [vp, vp, i32, vp],
+    "adh_route_compact": [vp, vp, i32, vp, vp],
+    "adh_gather_images": [vp, vp, vp, i32, i64, vp],
+    "adh_scatter_images": [vp, vp, vp, i32, i64, vp],
+    "adh_reduce_num_blocks": [i64],
+    "adh_l1_partial": [vp, vp, vp, i64, vp],
+    "adh_mse_partial": [vp, vp, vp, i64, vp],
+    "adh_sum_partials": [vp, vp, i32, f64, vp],
+    "adh_l1_bwd": [vp, vp, vp, i64, f32, vp, vp],
+    "adh_mse_bwd": [vp, vp, vp, i64, f32, vp, vp],
+    "adh_cross_entropy3": [vp, vp, vp, i32, vp, vp],
+    "adh_adam_step": [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32],
+    "adh_add_inplace": [vp, vp, vp, i64],
+    "adh_axpby_strided": [vp, vp, i32, vp, i32, i64, i32, f32, f32],
+    "adh_maxpool": [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp],
+    "adh_maxpool_bwd": [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32],
+    "adh_bilinear": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32],
+    "adh_bilinear_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32],
+}
+
+# functions that return a count / size rather than a status code
+_VALUE_FUNCS = {"adh_version", "adh_conv_lds_bytes", "adh_conv_num_blocks", "adh_bn_bwd_num_blocks",
+                "adh_cbam_pool_num_blocks", "adh_cbam_bwd_b_num_blocks", "adh_head_blend_bwd_num_blocks",
+                "adh_reduce_num_blocks"}
+
+_ERRORS = {-1: "ADH_E_ARG (bad argument: shape / alignment / null pointer)",
+           -2: "ADH_E_LAUNCH (hip kernel launch failed)",
+           -3: "ADH_E_UNSUPPORTED (configuration not supported by the kernels)"}
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once). Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C adam-dehaze_amd/csrc`). There is no CPU fallback on the product path.")
+        lib = C.CDLL(_LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def call(name: str, *args):
+    """Invoke a status-returning entry point on the current stream; raise on failure."""
+    rc = getattr(load(), name)(stream_ptr(), *args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERRORS.get(rc, rc)}")
+
+
+def value(name: str, *args) -> int:
+    """Invoke a query entry point (returns a count/size; negative = error)."""
+    assert name in _VALUE_FUNCS
+    rc = getattr(load(), name)(*args)
+    if rc < 0:
+        raise RuntimeError(f"{name} failed: {_ERRORS.get(rc, rc)}")
+    return rc
+
+
+def require_cuda(t: torch.Tensor, what: str = "input") -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"adam-dehaze_amd: {what} is on {t.device}; this implementation runs on MI355X through the HIP library only "
+            "(no CPU fallback). Move the module and its inputs to a cuda device.")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"adam-dehaze_amd: {what} must be float32, got {t.dtype}")

@@ -1,0 +1,539 @@
+// AttentionBlock (CBAM-style channel + spatial attention) forward / backward, gfx950.
+// Restates /root/reference models/dehazing/base_model.py:43-78 as HBM-streaming kernels over NHWC:
+//   forward  = pool pass (read x) + tiny MLP + spatial-stat pass (read x) + apply pass (read x, write out)
+//   backward = 3 streaming passes over (g, x) + two tiny kernels.
+// Reductions: per-pixel channel reductions use 8 lanes per pixel (128-B coalesced segments) and
+// wavefront shuffles; per-channel spatial reductions keep a channel quad per thread and combine
+// blocks in a fixed order (deterministic).  Arg-max ties resolve to the FIRST index like
+// torch.max / adaptive_max_pool2d on CPU (ReLU outputs contain exact zeros, so ties do occur).
+#include "common.h"
+
+#define POOL_PPB 1024
+
+extern "C" int adh_cbam_pool_num_blocks(int HW) { return adh_ceil_div(HW, POOL_PPB); }
+
+// partial[n][blk][2][C] (sum, max), partial_idx[n][blk][C]
+__global__ __launch_bounds__(256) void cbam_pool_partial_kernel(const float* __restrict__ x, int x_cs, int HW, int C,
+                                                                float* __restrict__ partial,
+                                                                int32_t* __restrict__ partial_idx, int nblk) {
+    __shared__ f32x4 rs[256];
+    __shared__ f32x4 rm[256];
+    __shared__ int ri[256][4];
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int CQ = C / 4;
+    const int R = 256 / CQ;
+    const int cq = threadIdx.x % CQ, prow = threadIdx.x / CQ;
+    const int c = cq * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int mi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    if (prow < R) {
+        const float* xn = x + (size_t)n * HW * x_cs;
+        const int p0 = blk * POOL_PPB;
+        const int p1 = adh_min_i(p0 + POOL_PPB, HW);
+        for (int p = p0 + prow; p < p1; p += R) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + c);
+            s += v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (v[j] > m[j]) {
+                    m[j] = v[j];
+                    mi[j] = p;
+                }
+        }
+    }
+    rs[threadIdx.x] = s;
+    rm[threadIdx.x] = m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ri[threadIdx.x][j] = mi[j];
+    __syncthreads();
+    if (threadIdx.x < CQ) {
+        f32x4 S = {0.f, 0.f, 0.f, 0.f};
+        f32x4 M = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int MI[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        for (int r = 0; r < R; ++r) {
+            const int t = r * CQ + threadIdx.x;
+            S += rs[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = rm[t][j];
+                const int vi = ri[t][j];
+                if (v > M[j] || (v == M[j] && vi < MI[j])) {
+                    M[j] = v;
+                    MI[j] = vi;
+                }
+            }
+        }
+        const size_t base = ((size_t)n * nblk + blk);
+        *reinterpret_cast<f32x4*>(partial + (base * 2 + 0) * C + c) = S;
+        *reinterpret_cast<f32x4*>(partial + (base * 2 + 1) * C + c) = M;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) partial_idx[base * C + c + j] = MI[j];
+    }
+}
+
+__global__ void cbam_pool_final_kernel(const float* __restrict__ partial, const int32_t* __restrict__ partial_idx,
+                                       int nblk, int HW, int C, float* __restrict__ pooled,
+                                       int32_t* __restrict__ amax_idx) {
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double S = 0.0;
+    float M = -INFINITY;
+    int MI = 0x7fffffff;
+    for (int b = 0; b < nblk; ++b) {
+        const size_t base = (size_t)n * nblk + b;
+        S += (double)partial[(base * 2 + 0) * C + c];
+        const float v = partial[(base * 2 + 1) * C + c];
+        const int vi = partial_idx[base * C + c];
+        if (v > M || (v == M && vi < MI)) {
+            M = v;
+            MI = vi;
+        }
+    }
+    pooled[((size_t)n * 2 + 0) * C + c] = (float)(S / (double)HW);
+    pooled[((size_t)n * 2 + 1) * C + c] = M;
+    amax_idx[(size_t)n * C + c] = MI;
+}
+
+extern "C" int adh_cbam_pool(void* stream, const float* x, int x_cs, int N, int HW, int C, float* partial,
+                             int32_t* partial_idx, int nblk, float* pooled, int32_t* amax_idx) {
+    if (!x || !partial || !partial_idx || !pooled || !amax_idx || N < 1 || HW < 1 || C < 4 || (C & 3) || C > 1024)
+        return ADH_E_ARG;
+    if (nblk != adh_cbam_pool_num_blocks(HW)) return ADH_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cbam_pool_partial_kernel, dim3(nblk, N), dim3(256), 0, s, x, x_cs, HW, C, partial, partial_idx,
+                       nblk);
+    hipLaunchKernelGGL(cbam_pool_final_kernel, dim3(adh_ceil_div(C, 128), N), dim3(128), 0, s, partial, partial_idx, nblk,
+                       HW, C, pooled, amax_idx);
+    return adh_check_launch();
+}
+
+// ca = sigmoid(W2 relu(W1 avg) + W2 relu(W1 max)); hidden[n][2][Ch] saved (post-relu)
+__global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                       const float* __restrict__ w2, int C, int Ch,
+                                                       float* __restrict__ ca, float* __restrict__ hidden) {
+    extern __shared__ float sm[];  // [2][C] pooled, [2][Ch] hidden
+    float* pv = sm;
+    float* hv = sm + 2 * C;
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) pv[i] = pooled[(size_t)n * 2 * C + i];
+    __syncthreads();
+    // hidden: one wave per (which, j) pair, strided
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int o = wave; o < 2 * Ch; o += (blockDim.x >> 6)) {
+        const int which = o / Ch, j = o - which * Ch;
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += w1[(size_t)j * C + c] * pv[which * C + c];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float hval = fmaxf(acc, 0.f);
+            hv[o] = hval;
+            hidden[(size_t)n * 2 * Ch + o] = hval;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int j = 0; j < Ch; ++j) acc += w2[(size_t)c * Ch + j] * hv[j];
+        float acc2 = 0.f;
+        for (int j = 0; j < Ch; ++j) acc2 += w2[(size_t)c * Ch + j] * hv[Ch + j];
+        ca[(size_t)n * C + c] = 1.0f / (1.0f + expf(-(acc + acc2)));
+    }
+}
+
+extern "C" int adh_cbam_mlp(void* stream, const float* pooled, const float* w1, const float* w2, int N, int C, int Ch,
+                            float* ca, float* hidden) {
+    if (!pooled || !w1 || !w2 || !ca || !hidden || N < 1 || C < 1 || Ch < 1) return ADH_E_ARG;
+    hipLaunchKernelGGL(cbam_mlp_kernel, dim3(N), dim3(256), (2 * C + 2 * Ch) * sizeof(float), (hipStream_t)stream, pooled,
+                       w1, w2, C, Ch, ca, hidden);
+    return adh_check_launch();
+}
+
+// per pixel: mean_c / max_c / first argmax_c of x*ca ; 8 lanes per pixel
+__global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const float* __restrict__ x, int x_cs,
+                                                                 const float* __restrict__ ca, int HW, int C,
+                                                                 float* __restrict__ smap, int32_t* __restrict__ cidx) {
+    const int n = blockIdx.y;
+    const int sub = threadIdx.x & 7;
+    const int CQ = C / 4;
+    const float* xn = x + (size_t)n * HW * x_cs;
+    const float* can = ca + (size_t)n * C;
+    const float invC = 1.0f / (float)C;
+    for (int p = blockIdx.x * 32 + (threadIdx.x >> 3); p < HW; p += gridDim.x * 32) {
+        float s = 0.f, m = -INFINITY;
+        int mi = 0x7fffffff;
+        for (int q = sub; q < CQ; q += 8) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + q * 4) *
+                            *reinterpret_cast<const f32x4*>(can + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s += v[j];
+                if (v[j] > m) {
+                    m = v[j];
+                    mi = q * 4 + j;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            const float om = __shfl_xor(m, o, 64);
+            const int oi = __shfl_xor(mi, o, 64);
+            if (om > m || (om == m && oi < mi)) {
+                m = om;
+                mi = oi;
+            }
+        }
+        if (sub == 0) {
+            smap[((size_t)n * HW + p) * 2 + 0] = s * invC;
+            smap[((size_t)n * HW + p) * 2 + 1] = m;
+            cidx[(size_t)n * HW + p] = mi;
+        }
+    }
+}
+
+extern "C" int adh_cbam_spatial_stats(void* stream, const float* x, int x_cs, const float* ca, int N, int HW, int C,
+                                      float* smap, int32_t* cidx) {
+    if (!x || !ca || !smap || !cidx || N < 1 || HW < 1 || C < 4 || (C & 3)) return ADH_E_ARG;
+    const int blocks = adh_min_i(adh_ceil_div(HW, 32), 2048);
+    hipLaunchKernelGGL(cbam_spatial_stats_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, x, x_cs, ca, HW, C,
+                       smap, cidx);
+    return adh_check_launch();
+}
+
+// sa = sigmoid(conv7x7(smap)); out = x*ca*sa.  Block = 64 consecutive pixels of one row.
+__global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict__ x, int x_cs,
+                                                         const float* __restrict__ ca, const float* __restrict__ smap,
+                                                         const float* __restrict__ wsp, int H, int W, int C,
+                                                         float* __restrict__ sa, float* __restrict__ out, int out_cs) {
+    __shared__ float s_sa[64];
+    __shared__ float s_w[98];
+    const int n = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 64;
+    if (threadIdx.x < 98) s_w[threadIdx.x] = wsp[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int xx = x0 + threadIdx.x;
+        float v = 0.f;
+        if (xx < W) {
+            const float* sm = smap + (size_t)n * H * W * 2;
+            for (int ky = 0; ky < 7; ++ky) {
+                const int yy = y + ky - 3;
+                if (yy < 0 || yy >= H) continue;
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int xs = xx + kx - 3;
+                    if (xs < 0 || xs >= W) continue;
+                    const float* q = sm + ((size_t)yy * W + xs) * 2;
+                    v += q[0] * s_w[ky * 7 + kx] + q[1] * s_w[49 + ky * 7 + kx];
+                }
+            }
+            v = 1.0f / (1.0f + expf(-v));
+            sa[((size_t)n * H + y) * W + xx] = v;
+        }
+        s_sa[threadIdx.x] = v;
+    }
+    __syncthreads();
+    const int CQ = C / 4;
+    const int npx = adh_min_i(64, W - x0);
+    const size_t rowbase = ((size_t)n * H + y) * W + x0;
+    const float* can = ca + (size_t)n * C;
+    for (int item = threadIdx.x; item < npx * CQ; item += 256) {
+        const int p = item / CQ, q = item - p * CQ;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (rowbase + p) * x_cs + q * 4) *
+                        *reinterpret_cast<const f32x4*>(can + q * 4) * s_sa[p];
+        *reinterpret_cast<f32x4*>(out + (rowbase + p) * out_cs + q * 4) = v;
+    }
+}
+
+extern "C" int adh_cbam_apply(void* stream, const float* x, int x_cs, const float* ca, const float* smap,
+                              const float* wsp, int N, int H, int W, int C, float* sa, float* out, int out_cs) {
+    if (!x || !ca || !smap || !wsp || !sa || !out || N < 1 || C < 4 || (C & 3) || H > 65535 || N > 65535) return ADH_E_ARG;
+    hipLaunchKernelGGL(cbam_apply_kernel, dim3(adh_ceil_div(W, 64), H, N), dim3(256), 0, (hipStream_t)stream, x, x_cs, ca,
+                       smap, wsp, H, W, C, sa, out, out_cs);
+    return adh_check_launch();
+}
+
+// ------------------------------------------- backward ---------------------------------------------
+// A: gsa_pre[n][hw] = (sum_c g*x*ca) * sa*(1-sa)
+__global__ __launch_bounds__(256) void cbam_bwd_a_kernel(const float* __restrict__ g, int g_cs,
+                                                         const float* __restrict__ x, int x_cs,
+                                                         const float* __restrict__ ca, const float* __restrict__ sa,
+                                                         int HW, int C, float* __restrict__ gsa_pre) {
+    const int n = blockIdx.y;
+    const int sub = threadIdx.x & 7;
+    const int CQ = C / 4;
+    const float* xn = x + (size_t)n * HW * x_cs;
+    const float* gn = g + (size_t)n * HW * g_cs;
+    const float* can = ca + (size_t)n * C;
+    for (int p = blockIdx.x * 32 + (threadIdx.x >> 3); p < HW; p += gridDim.x * 32) {
+        float s = 0.f;
+        for (int q = sub; q < CQ; q += 8) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + q * 4) *
+                            *reinterpret_cast<const f32x4*>(can + q * 4) *
+                            *reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + q * 4);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (sub == 0) {
+            const float a = sa[(size_t)n * HW + p];
+            gsa_pre[(size_t)n * HW + p] = s * a * (1.f - a);
+        }
+    }
+}
+
+extern "C" int adh_cbam_bwd_a(void* stream, const float* g, int g_cs, const float* x, int x_cs, const float* ca,
+                              const float* sa, int N, int HW, int C, float* gsa_pre) {
+    if (!g || !x || !ca || !sa || !gsa_pre || N < 1 || HW < 1 || C < 4 || (C & 3)) return ADH_E_ARG;
+    const int blocks = adh_min_i(adh_ceil_div(HW, 32), 2048);
+    hipLaunchKernelGGL(cbam_bwd_a_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, g, g_cs, x, x_cs, ca, sa, HW,
+                       C, gsa_pre);
+    return adh_check_launch();
+}
+
+// B: gsmap = conv7x7^T(gsa_pre) ; dwsp partial sums.  One thread per pixel, 256 pixels per block.
+extern "C" int adh_cbam_bwd_b_num_blocks(int N, int H, int W) { return adh_ceil_div((int64_t)N * H * W, 256); }
+
+__global__ __launch_bounds__(256) void cbam_bwd_b_kernel(const float* __restrict__ gsa_pre,
+                                                         const float* __restrict__ smap, const float* __restrict__ wsp,
+                                                         int N, int H, int W, float* __restrict__ gsmap,
+                                                         float* __restrict__ dwsp_partial) {
+    __shared__ float s_w[98];
+    __shared__ float s_acc[4][98];
+    if (threadIdx.x < 98) s_w[threadIdx.x] = wsp[threadIdx.x];
+    __syncthreads();
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = idx < total;
+    int n = 0, y = 0, xx = 0;
+    if (valid) {
+        xx = (int)(idx % W);
+        const int64_t r = idx / W;
+        y = (int)(r % H);
+        n = (int)(r / H);
+    }
+    const float* gp = gsa_pre + (size_t)n * H * W;
+    const float* sm = smap + (size_t)n * H * W * 2;
+    const float gs_here = valid ? gp[(size_t)y * W + xx] : 0.f;
+    float g0 = 0.f, g1 = 0.f;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int ky = 0; ky < 7; ++ky) {
+        for (int kx = 0; kx < 7; ++kx) {
+            // transposed conv: this input pixel (y,xx) contributed to output (y-ky+3, xx-kx+3) with weight [ky][kx]
+            const int oy = y - ky + 3, ox = xx - kx + 3;
+            if (valid && oy >= 0 && oy < H && ox >= 0 && ox < W) {
+                const float go = gp[(size_t)oy * W + ox];
+                g0 += go * s_w[ky * 7 + kx];
+                g1 += go * s_w[49 + ky * 7 + kx];
+            }
+            // weight gradient: output pixel (y,xx) read smap at (y+ky-3, xx+kx-3)
+            const int iy = y + ky - 3, ix = xx + kx - 3;
+            float a0 = 0.f, a1 = 0.f;
+            if (valid && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const float* q = sm + ((size_t)iy * W + ix) * 2;
+                a0 = q[0] * gs_here;
+                a1 = q[1] * gs_here;
+            }
+            a0 = wave_sum(a0);
+            a1 = wave_sum(a1);
+            if (lane == 0) {
+                s_acc[wave][ky * 7 + kx] = a0;
+                s_acc[wave][49 + ky * 7 + kx] = a1;
+            }
+        }
+    }
+    if (valid) {
+        gsmap[idx * 2 + 0] = g0;
+        gsmap[idx * 2 + 1] = g1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 98)
+        dwsp_partial[(size_t)blockIdx.x * 98 + threadIdx.x] =
+            (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x]) + (s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void cbam_dwsp_final_kernel(const float* __restrict__ partial, int nblk, float* dwsp,
+                                                              int accumulate) {
+    __shared__ double red[256];
+    const int o = blockIdx.x;  // 0..97
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partial[(size_t)b * 98 + o];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dwsp[o] = accumulate ? dwsp[o] + (float)red[0] : (float)red[0];
+}
+
+extern "C" int adh_cbam_bwd_b(void* stream, const float* gsa_pre, const float* smap, const float* wsp, int N, int H,
+                              int W, float* gsmap, float* dwsp_partial, int nblk, float* dwsp, int accumulate) {
+    if (!gsa_pre || !smap || !wsp || !gsmap || !dwsp_partial || !dwsp) return ADH_E_ARG;
+    if (nblk != adh_cbam_bwd_b_num_blocks(N, H, W)) return ADH_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cbam_bwd_b_kernel, dim3(nblk), dim3(256), 0, s, gsa_pre, smap, wsp, N, H, W, gsmap, dwsp_partial);
+    hipLaunchKernelGGL(cbam_dwsp_final_kernel, dim3(98), dim3(256), 0, s, dwsp_partial, nblk, dwsp, accumulate);
+    return adh_check_launch();
+}
+
+// gx1 for a channel quad of one pixel
+__device__ __forceinline__ f32x4 cbam_gx1(const f32x4 g, float sa, float gmean_over_c, float gmax, int cidx, int c) {
+    f32x4 r = g * sa + gmean_over_c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (c + j == cidx) r[j] += gmax;
+    return r;
+}
+
+// C: gca_partial[n][blk][C] = sum_hw gx1 * x
+__global__ __launch_bounds__(256) void cbam_bwd_c_kernel(const float* __restrict__ g, int g_cs,
+                                                         const float* __restrict__ x, int x_cs,
+                                                         const float* __restrict__ sa, const float* __restrict__ gsmap,
+                                                         const int32_t* __restrict__ cidx, int HW, int C,
+                                                         float* __restrict__ gca_partial, int nblk) {
+    __shared__ f32x4 rs[256];
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int CQ = C / 4;
+    const int R = 256 / CQ;
+    const int cq = threadIdx.x % CQ, prow = threadIdx.x / CQ;
+    const int c = cq * 4;
+    const float invC = 1.0f / (float)C;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (prow < R) {
+        const float* xn = x + (size_t)n * HW * x_cs;
+        const float* gn = g + (size_t)n * HW * g_cs;
+        const int p0 = blk * POOL_PPB;
+        const int p1 = adh_min_i(p0 + POOL_PPB, HW);
+        for (int p = p0 + prow; p < p1; p += R) {
+            const size_t pp = (size_t)n * HW + p;
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + c);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + c);
+            const f32x4 gx1 = cbam_gx1(gv, sa[pp], gsmap[pp * 2 + 0] * invC, gsmap[pp * 2 + 1], cidx[pp], c);
+            s += gx1 * xv;
+        }
+    }
+    rs[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < CQ) {
+        f32x4 S = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r) S += rs[r * CQ + threadIdx.x];
+        *reinterpret_cast<f32x4*>(gca_partial + ((size_t)n * nblk + blk) * C + c) = S;
+    }
+}
+
+extern "C" int adh_cbam_bwd_c(void* stream, const float* g, int g_cs, const float* x, int x_cs, const float* sa,
+                              const float* gsmap, const int32_t* cidx, int N, int HW, int C, float* gca_partial,
+                              int nblk) {
+    if (!g || !x || !sa || !gsmap || !cidx || !gca_partial || C < 4 || (C & 3) || C > 1024) return ADH_E_ARG;
+    if (nblk != adh_cbam_pool_num_blocks(HW)) return ADH_E_ARG;
+    hipLaunchKernelGGL(cbam_bwd_c_kernel, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, g, g_cs, x, x_cs, sa, gsmap,
+                       cidx, HW, C, gca_partial, nblk);
+    return adh_check_launch();
+}
+
+// D: tiny; single block, images processed in order (deterministic weight-gradient accumulation)
+__global__ __launch_bounds__(256) void cbam_bwd_d_kernel(const float* __restrict__ gca_partial, int nblk,
+                                                         const float* __restrict__ ca, const float* __restrict__ pooled,
+                                                         const float* __restrict__ hidden, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, int N, int C, int Ch,
+                                                         float* __restrict__ gpool, float* dw1, float* dw2,
+                                                         int accumulate) {
+    extern __shared__ float sm[];
+    float* gpre = sm;            // [C]
+    float* ghid = sm + C;        // [2][Ch]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int n = 0; n < N; ++n) {
+        // g_pre[c] = (sum_blk partial) * ca*(1-ca)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            double s = 0.0;
+            for (int b = 0; b < nblk; ++b) s += (double)gca_partial[((size_t)n * nblk + b) * C + c];
+            const float a = ca[(size_t)n * C + c];
+            gpre[c] = (float)s * a * (1.f - a);
+        }
+        __syncthreads();
+        // hidden grads (through W2 and the relu masks)
+        for (int o = wave; o < 2 * Ch; o += nw) {
+            const int which = o / Ch, j = o - which * Ch;
+            float acc = 0.f;
+            for (int c = lane; c < C; c += 64) acc += w2[(size_t)c * Ch + j] * gpre[c];
+            acc = wave_sum(acc);
+            if (lane == 0) ghid[o] = hidden[(size_t)n * 2 * Ch + o] > 0.f ? acc : 0.f;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float ga = 0.f, gm = 0.f;
+            for (int j = 0; j < Ch; ++j) {
+                const float w = w1[(size_t)j * C + c];
+                ga += w * ghid[j];
+                gm += w * ghid[Ch + j];
+            }
+            gpool[((size_t)n * 2 + 0) * C + c] = ga;
+            gpool[((size_t)n * 2 + 1) * C + c] = gm;
+        }
+        // weight grads
+        const bool first = (n == 0) && !accumulate;
+        for (int i = threadIdx.x; i < C * Ch; i += blockDim.x) {
+            const int c = i / Ch, j = i - c * Ch;  // dw2 [C][Ch]
+            const float v = gpre[c] * (hidden[(size_t)n * 2 * Ch + j] + hidden[(size_t)n * 2 * Ch + Ch + j]);
+            dw2[i] = first ? v : dw2[i] + v;
+        }
+        for (int i = threadIdx.x; i < Ch * C; i += blockDim.x) {
+            const int j = i / C, c = i - j * C;  // dw1 [Ch][C]
+            const float v = ghid[j] * pooled[((size_t)n * 2 + 0) * C + c] + ghid[Ch + j] * pooled[((size_t)n * 2 + 1) * C + c];
+            dw1[i] = first ? v : dw1[i] + v;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int adh_cbam_bwd_d(void* stream, const float* gca_partial, int nblk, const float* ca, const float* pooled,
+                              const float* hidden, const float* w1, const float* w2, int N, int C, int Ch, float* gpool,
+                              float* dw1, float* dw2, int accumulate) {
+    if (!gca_partial || !ca || !pooled || !hidden || !w1 || !w2 || !gpool || !dw1 || !dw2) return ADH_E_ARG;
+    hipLaunchKernelGGL(cbam_bwd_d_kernel, dim3(1), dim3(256), (C + 2 * Ch) * sizeof(float), (hipStream_t)stream,
+                       gca_partial, nblk, ca, pooled, hidden, w1, w2, N, C, Ch, gpool, dw1, dw2, accumulate);
+    return adh_check_launch();
+}
+
+// E: gx = gx1*ca + gpool.avg/HW + gpool.max*[hw==amax_idx]
+__global__ __launch_bounds__(256) void cbam_bwd_e_kernel(const float* __restrict__ g, int g_cs,
+                                                         const float* __restrict__ ca, const float* __restrict__ sa,
+                                                         const float* __restrict__ gsmap,
+                                                         const int32_t* __restrict__ cidx,
+                                                         const float* __restrict__ gpool,
+                                                         const int32_t* __restrict__ amax_idx, int HW, int C,
+                                                         float* __restrict__ gx, int gx_cs) {
+    const int n = blockIdx.y;
+    const int CQ = C / 4;
+    const float invC = 1.0f / (float)C, invHW = 1.0f / (float)HW;
+    const int64_t total = (int64_t)HW * CQ;
+    const float* gn = g + (size_t)n * HW * g_cs;
+    float* gxn = gx + (size_t)n * HW * gx_cs;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(idx / CQ);
+        const int c = (int)(idx - (int64_t)p * CQ) * 4;
+        const size_t pp = (size_t)n * HW + p;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + c);
+        f32x4 r = cbam_gx1(gv, sa[pp], gsmap[pp * 2 + 0] * invC, gsmap[pp * 2 + 1], cidx[pp], c);
+        r = r * *reinterpret_cast<const f32x4*>(ca + (size_t)n * C + c) +
+            *reinterpret_cast<const f32x4*>(gpool + ((size_t)n * 2 + 0) * C + c) * invHW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (amax_idx[(size_t)n * C + c + j] == p) r[j] += gpool[((size_t)n * 2 + 1) * C + c + j];
+        *reinterpret_cast<f32x4*>(gxn + (size_t)p * gx_cs + c) = r;
+    }
+}
+
+extern "C" int adh_cbam_bwd_e(void* stream, const float* g, int g_cs, const float* x, int x_cs, const float* ca,
+                              const float* sa, const float* gsmap, const int32_t* cidx, const float* gpool,
+                              const int32_t* amax_idx, int N, int HW, int C, float* gx, int gx_cs) {
+    (void)x;
+    (void)x_cs;
+    if (!g || !ca || !sa || !gsmap || !cidx || !gpool || !amax_idx || !gx || C < 4 || (C & 3)) return ADH_E_ARG;
+    const int blocks = adh_min_i(adh_ceil_div((int64_t)HW * (C / 4), 256), 4096);
+    hipLaunchKernelGGL(cbam_bwd_e_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, g, g_cs, ca, sa, gsmap, cidx,
+                       gpool, amax_idx, HW, C, gx, gx_cs);
+    return adh_check_launch();
+}

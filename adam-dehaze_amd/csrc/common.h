@@ -1,0 +1,53 @@
+// Shared device/host helpers for libadamdehaze_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/adam_dehaze_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ADH_WAVE 64
+
+static inline int adh_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADH_OK : ADH_E_LAUNCH;
+}
+
+__host__ __device__ static inline int adh_min_i(int a, int b) { return a < b ? a : b; }
+__host__ __device__ static inline int adh_max_i(int a, int b) { return a > b ? a : b; }
+static inline int adh_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int adh_round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// Tap-extent helpers (host + device)
+__host__ __device__ static inline int adh_tap_min(int d0, int step, int k) {
+    int e = d0 + (k - 1) * step;
+    return d0 < e ? d0 : e;
+}
+__host__ __device__ static inline int adh_tap_max(int d0, int step, int k) {
+    int e = d0 + (k - 1) * step;
+    return d0 > e ? d0 : e;
+}
+
+// Geometry of one conv launch, derived on the host and passed by value.
+struct ConvGeom {
+    int dmin_y, dmin_x;     // smallest tap offsets
+    int halo_h, halo_w;     // input footprint of one TH x 32 tile
+    int npx, npxp;          // halo pixels, padded (odd) pitch
+    int tiles_x, tiles_y;
+    int KC, KQ_log2;        // channels per LDS chunk, log2(KC/4)
+    int KQtot;              // padded Cin / 4
+    int TH;                 // tile rows (8 for forward)
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }

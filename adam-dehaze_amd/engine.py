@@ -1,0 +1,549 @@
+"""Forward/backward engine over the HIP library.
+
+A branch forward is a sequence of fused ops on fp32 NHWC activations (`Act`); every op launches
+kernels through the C ABI (`_hip.call`) and, when gradients are needed, appends a backward closure to
+the tape.  `Engine.backward()` replays the tape in reverse.  torch supplies device memory, the HIP
+stream and the outer autograd hook (`functional.BranchFunction`); no torch arithmetic runs here.
+
+Reference semantics cited per op (paths under /root/reference).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _hip as H
+from ._hip import ConvDesc, WLayout
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class Act:
+    """An NHWC activation: `t` is a [N,H,W,C] float32 cuda tensor whose last-dim stride is 1 and whose
+    pixel stride (t.stride(2)) may exceed C (channel slice of a wider buffer).  `C` is the logical
+    channel count; `t.shape[3]` may be larger for the small padded tensors (3->8, 1->4 channels)."""
+
+    __slots__ = ("t", "C", "grad", "needs_grad")
+
+    def __init__(self, t: torch.Tensor, C: Optional[int] = None, needs_grad: bool = True):
+        assert t.dim() == 4 and t.stride(3) == 1
+        self.t = t
+        self.C = t.shape[3] if C is None else C
+        self.grad: Optional[torch.Tensor] = None
+        self.needs_grad = needs_grad
+
+    @property
+    def N(self): return self.t.shape[0]
+    @property
+    def Hh(self): return self.t.shape[1]
+    @property
+    def Ww(self): return self.t.shape[2]
+    @property
+    def cs(self): return self.t.stride(2)
+    @property
+    def pixels(self): return self.t.shape[0] * self.t.shape[1] * self.t.shape[2]
+
+
+def _check_dense_pixels(t: torch.Tensor):
+    # rows and images must be dense in units of the pixel stride
+    cs = t.stride(2)
+    assert t.stride(1) == t.shape[2] * cs and t.stride(0) == t.shape[1] * t.shape[2] * cs, "unsupported activation strides"
+
+
+def new_act(N, Hh, Ww, C, device, alloc_C: Optional[int] = None, zero: bool = False) -> Act:
+    ac = C if alloc_C is None else alloc_C
+    t = (torch.zeros if zero else torch.empty)((N, Hh, Ww, ac), device=device, dtype=torch.float32)
+    return Act(t, C)
+
+
+class BNState:
+    """Parameters/buffers of one BatchNorm2d, by reference to the owning module's tensors."""
+    __slots__ = ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")
+
+    def __init__(self, weight, bias, running_mean, running_var, num_batches_tracked):
+        self.weight, self.bias = weight, bias
+        self.running_mean, self.running_var = running_mean, running_var
+        self.num_batches_tracked = num_batches_tracked
+
+
+class Engine:
+    def __init__(self, device: torch.device, record: bool):
+        self.device = device
+        self.record = record
+        self.tape: List[Callable[[], None]] = []
+        self.param_grads: Dict[int, torch.Tensor] = {}   # id(param) -> grad
+        self.params: Dict[int, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _f(self, *shape, zero=False):
+        return (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=torch.float32)
+
+    def add_param_grad(self, p: torch.Tensor, g: torch.Tensor):
+        k = id(p)
+        if k in self.param_grads:
+            H.call("adh_add_inplace", self.param_grads[k].data_ptr(), g.data_ptr(), g.numel())
+        else:
+            self.param_grads[k] = g
+            self.params[k] = p
+
+    def accum(self, act: Act, g: torch.Tensor):
+        """act.grad (+)= g ; g is [N,H,W,>=C] possibly strided."""
+        if not act.needs_grad:
+            return
+        if act.grad is None:
+            act.grad = g
+        else:
+            H.call("adh_axpby_strided", act.grad.data_ptr(), act.grad.stride(2), g.data_ptr(), g.stride(2),
+                   act.pixels, _round_up(act.C, 4), 1.0, 1.0)
+
+    def backward(self):
+        while self.tape:
+            self.tape.pop()()
+
+    # ------------------------------------------------------------------ layout at the boundary
+    def image_to_nhwc8(self, x: torch.Tensor) -> Act:
+        N, Cc, Hh, Ww = x.shape
+        assert Cc == 3
+        out = self._f(N, Hh, Ww, 8)
+        H.call("adh_image_to_nhwc8", x.data_ptr(), N, Hh, Ww, out.data_ptr())
+        return Act(out, 8, needs_grad=False)
+
+    # ------------------------------------------------------------------ convolution family
+    @staticmethod
+    def _conv_desc(x: Act, Cin: int, out_t: torch.Tensor, Cout: int, NcP: int, VH, VW, KH, KW, in_s, out_s, out_o,
+                   dy0, dx0, dstep) -> ConvDesc:
+        d = ConvDesc()
+        d.in_ = x.t.data_ptr()
+        d.N, d.IH, d.IW, d.Cin, d.in_cstride = x.N, x.Hh, x.Ww, Cin, x.cs
+        d.out = out_t.data_ptr()
+        d.OH, d.OW, d.Cout, d.out_cstride = out_t.shape[1], out_t.shape[2], Cout, out_t.stride(2)
+        d.VH, d.VW = VH, VW
+        d.in_sy = d.in_sx = in_s
+        d.out_sy = d.out_sx = out_s
+        d.out_oy, d.out_ox = out_o
+        d.KH, d.KW = KH, KW
+        d.dy0, d.dx0 = dy0, dx0
+        d.dstep_y = d.dstep_x = dstep
+        d.act = H.ACT_NONE
+        d.NcP = NcP
+        return d
+
+    def _pack(self, w: torch.Tensor, L: WLayout) -> torch.Tensor:
+        KQ = _round_up(L.K, 8) // 4
+        NcP = _round_up(L.Nc, 32)
+        wp = self._f(L.KHt * L.KWt * KQ * NcP * 4)
+        H.call("adh_pack_weights", w.data_ptr(), C.byref(L), wp.data_ptr())
+        return wp
+
+    @staticmethod
+    def _launch_plan(kind: str, k: int, stride: int, pad: int, w: torch.Tensor, direction: str):
+        """Return a list of launches [(WLayout, geometry dict)] realising one conv layer's forward
+        ('fwd'), data gradient ('dgrad') in the gather form.  Weight gradients reuse the 'fwd' plan.
+
+        conv  : Conv2d weight [Cout,Cin,k,k], stride 1 or 2      (base_model.py:11-13)
+        convT : ConvTranspose2d weight [Cin,Cout,4,4], s2 p1      (medium_intensity.py:53,63)
+        geometry: in_s, out_s, out_o, dy0, dx0, dstep, KH, KW, vgrid ('out'|'in'|'out_half')
+        """
+        plans = []
+        if kind == "conv":
+            Cout, Cin = w.shape[0], w.shape[1]
+            kk = k * k
+            if direction == "fwd":
+                L = WLayout(Cin, Cout, k, k, 0, k, 1, kk, Cin * kk)
+                plans.append((L, dict(in_s=stride, out_s=1, out_o=(0, 0), dy0=-pad, dx0=-pad, dstep=1, KH=k, KW=k,
+                                      vgrid="out")))
+            elif stride == 1:   # dgrad of a stride-1 conv: correlation with taps walked backwards
+                L = WLayout(Cout, Cin, k, k, 0, k, 1, Cin * kk, kk)
+                plans.append((L, dict(in_s=1, out_s=1, out_o=(0, 0), dy0=pad, dx0=pad, dstep=-1, KH=k, KW=k,
+                                      vgrid="out")))
+            else:               # dgrad of k4 s2 p1 conv = transposed-conv form, one launch per output parity
+                assert k == 4 and stride == 2 and pad == 1
+                for py in range(2):
+                    for px in range(2):
+                        L = WLayout(Cout, Cin, 2, 2, (1 - py) * 4 + (1 - px), 8, 2, Cin * kk, kk)
+                        plans.append((L, dict(in_s=1, out_s=2, out_o=(py, px), dy0=py, dx0=px, dstep=-1, KH=2, KW=2,
+                                              vgrid="in")))
+        else:
+            assert kind == "convT" and k == 4 and stride == 2 and pad == 1
+            Cin, Cout = w.shape[0], w.shape[1]
+            if direction == "fwd":
+                for py in range(2):
+                    for px in range(2):
+                        L = WLayout(Cin, Cout, 2, 2, (1 - py) * 4 + (1 - px), 8, 2, Cout * 16, 16)
+                        plans.append((L, dict(in_s=1, out_s=2, out_o=(py, px), dy0=py, dx0=px, dstep=-1, KH=2, KW=2,
+                                              vgrid="in")))
+            else:               # dgrad of convT = k4 s2 p1 conv of the output gradient
+                L = WLayout(Cout, Cin, 4, 4, 0, 4, 1, 16, Cout * 16)
+                plans.append((L, dict(in_s=2, out_s=1, out_o=(0, 0), dy0=-1, dx0=-1, dstep=1, KH=4, KW=4,
+                                      vgrid="out")))
+        return plans
+
+    def _run_gather(self, plans, src: Act, dst_t: torch.Tensor, dstC: int, w: torch.Tensor, scale=None, shift=None,
+                    residual: Optional[torch.Tensor] = None, act=H.ACT_NONE, want_stats=False):
+        """Launch every plan of one layer; returns (stats partials or None, number of stat rows)."""
+        descs = []
+        total_blocks = 0
+        for L, gm in plans:
+            NcP = _round_up(L.Nc, 32)
+            Kp = _round_up(L.K, 8)
+            assert src.t.shape[3] >= Kp or src.cs >= Kp, "input activation narrower than the padded contraction"
+            if gm["vgrid"] == "in":   # one output-parity class of a stride-2 transposed form
+                VH = (dst_t.shape[1] - gm["out_o"][0] + 1) // 2
+                VW = (dst_t.shape[2] - gm["out_o"][1] + 1) // 2
+            else:
+                VH, VW = dst_t.shape[1], dst_t.shape[2]
+            d = self._conv_desc(src, Kp, dst_t, dstC, NcP, VH, VW, gm["KH"], gm["KW"], gm["in_s"], gm["out_s"],
+                                gm["out_o"], gm["dy0"], gm["dx0"], gm["dstep"])
+            wp = self._pack(w, L)   # keep alive until the launch below is enqueued
+            d.wp = wp.data_ptr()
+            d.scale = H.ptr(scale)
+            d.shift = H.ptr(shift)
+            if residual is not None:
+                d.residual = residual.data_ptr()
+                d.res_cstride = residual.stride(2)
+            d.act = act
+            nb = H.value("adh_conv_num_blocks", C.byref(d))
+            descs.append((d, nb, wp))
+            total_blocks += nb
+        stats = None
+        if want_stats:
+            NcP = descs[0][0].NcP
+            stats = self._f(total_blocks, 2, NcP)
+        row = 0
+        for d, nb, _wp in descs:
+            if stats is not None:
+                d.stats = stats.data_ptr() + row * 2 * d.NcP * 4
+            H.call("adh_conv_forward", C.byref(d))
+            row += nb
+        return stats, total_blocks
+
+    def _wgrad(self, plans, x: Act, g_y: torch.Tensor, gC: int, w: torch.Tensor) -> torch.Tensor:
+        """Weight gradient in the parameter's own layout (OIHW / IOHW)."""
+        dw = self._f(*w.shape)
+        for L, gm in plans:
+            NcP = _round_up(L.Nc, 32)
+            KP = _round_up(L.K, 32)
+            Cin4 = _round_up(L.K, 4)
+            if gm["vgrid"] == "in":
+                VH = (g_y.shape[1] - gm["out_o"][0] + 1) // 2
+                VW = (g_y.shape[2] - gm["out_o"][1] + 1) // 2
+            else:
+                VH, VW = g_y.shape[1], g_y.shape[2]
+            d = self._conv_desc(x, Cin4, g_y, _round_up(gC, 4), NcP, VH, VW, gm["KH"], gm["KW"], gm["in_s"],
+                                gm["out_s"], gm["out_o"], gm["dy0"], gm["dx0"], gm["dstep"])
+            ntiles_est = x.N * ((VH + 3) // 4) * ((VW + 31) // 32)
+            ygroups = (KP // 32) * max(1, NcP // 96)
+            nsplit = max(1, min(ntiles_est, 1536 // max(1, ygroups), 512))
+            T = gm["KH"] * gm["KW"]
+            slab_elems = nsplit * T * KP * NcP
+            # cap the slab at 1 GiB
+            while slab_elems * 4 > (1 << 30) and nsplit > 1:
+                nsplit //= 2
+                slab_elems = nsplit * T * KP * NcP
+            slab = self._f(slab_elems)
+            H.call("adh_conv_wgrad", C.byref(d), slab.data_ptr(), nsplit)
+            H.call("adh_wgrad_reduce", slab.data_ptr(), nsplit, KP, NcP, C.byref(L), dw.data_ptr(), 0)
+        return dw
+
+    def _channel_sum(self, g: torch.Tensor, Cc: int) -> torch.Tensor:
+        """sum over pixels of g[..., :Cc] (bias gradient) using the BN-backward reduction kernels."""
+        P = g.shape[0] * g.shape[1] * g.shape[2]
+        C4 = _round_up(Cc, 4)
+        nblk = H.value("adh_bn_bwd_num_blocks", P, C4)
+        partial = self._f(nblk, 2, C4)
+        zeros = self._f(C4, zero=True)
+        H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), None, 0, H.ACT_NONE, g.data_ptr(), g.stride(2),
+               zeros.data_ptr(), zeros.data_ptr(), partial.data_ptr(), P, C4)
+        dbeta = self._f(C4)
+        coef = self._f(3, C4)
+        H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), None, zeros.data_ptr(), None,
+               dbeta.data_ptr(), 0, coef.data_ptr())
+        return dbeta[:Cc]
+
+    def conv(self, x: Act, w: torch.Tensor, b: Optional[torch.Tensor], bn: Optional[BNState], *, kind: str = "conv",
+             k: int = 3, stride: int = 1, pad: int = 1, relu: bool = True, residual: Optional[Act] = None,
+             training: bool = False, out: Optional[torch.Tensor] = None, out_alloc_C: Optional[int] = None) -> Act:
+        """ConvBlock / ConvTranspose+BN+ReLU / bare Conv2d as one fused op
+        (base_model.py:4-24,26-41; medium_intensity.py:52-56).  `residual` is added after BN and before the
+        ReLU (ResidualBlock tail).  `out`: optional preallocated [N,OH,OW,>=Cout] view to write into."""
+        if kind == "conv":
+            Cout = w.shape[0]
+            OH = (x.Hh + 2 * pad - k) // stride + 1
+            OW = (x.Ww + 2 * pad - k) // stride + 1
+        else:
+            Cout = w.shape[1]
+            OH, OW = x.Hh * 2, x.Ww * 2
+        N = x.N
+        act_code = H.ACT_RELU if relu else H.ACT_NONE
+        if out is None:
+            # channel allocation is a multiple of 8 (zero padded) so the tensor can feed the MFMA kernels
+            ac = out_alloc_C if out_alloc_C is not None else _round_up(Cout, 8)
+            out = self._f(N, OH, OW, ac, zero=(ac != Cout))
+        _check_dense_pixels(out)
+        plans = self._launch_plan(kind, k, stride, pad, w, "fwd")
+        res_t = residual.t if residual is not None else None
+        P = N * OH * OW
+
+        if bn is not None and training:
+            # raw conv output + per-block statistics, then normalise (+residual, ReLU) in one streaming pass
+            y = self._f(N, OH, OW, _round_up(Cout, 4))
+            stats, nblk = self._run_gather(plans, x, y, Cout, w, shift=b, want_stats=True)
+            scale, shift = self._f(Cout), self._f(Cout)
+            mean, invstd = self._f(Cout), self._f(Cout)
+            NcP = _round_up(Cout, 32)
+            H.call("adh_bn_finalize", stats.data_ptr(), nblk, NcP, Cout, float(P), bn.weight.data_ptr(),
+                   bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            H.call("adh_bn_apply", y.data_ptr(), y.stride(2), scale.data_ptr(), shift.data_ptr(), H.ptr(res_t),
+                   res_t.stride(2) if res_t is not None else 0, act_code, out.data_ptr(), out.stride(2), P, Cout)
+            saved = ("train", y, mean, invstd)
+        elif bn is not None:
+            scale, shift = self._f(Cout), self._f(Cout)
+            H.call("adh_bn_fold_eval", Cout, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                   bn.running_var.data_ptr(), BN_EPS, H.ptr(b), scale.data_ptr(), shift.data_ptr())
+            self._run_gather(plans, x, out, Cout, w, scale=scale, shift=shift, residual=res_t, act=act_code)
+            saved = ("eval", scale)
+        else:
+            self._run_gather(plans, x, out, Cout, w, shift=b, residual=res_t, act=act_code)
+            saved = ("plain",)
+
+        o = Act(out, Cout)
+        if self.record:
+            self.tape.append(lambda: self._conv_backward(x, w, b, bn, kind, k, stride, pad, relu, residual, o, saved))
+        return o
+
+    def _conv_backward(self, x: Act, w, b, bn, kind, k, stride, pad, relu, residual, o: Act, saved):
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        Cout = o.C
+        C4 = _round_up(Cout, 4)
+        N, OH, OW = o.N, o.Hh, o.Ww
+        P = N * OH * OW
+        act_code = H.ACT_RELU if relu else H.ACT_NONE
+        mode = saved[0]
+        C8 = _round_up(Cout, 8)
+        g_y = self._f(N, OH, OW, C8, zero=(C8 != C4))   # padded channels must be finite zeros (dgrad reads them)
+        g_res = None
+        if residual is not None and residual.needs_grad:
+            g_res = self._f(N, OH, OW, C4)
+        if mode == "train":
+            _, y, mean, invstd = saved
+            nblk = H.value("adh_bn_bwd_num_blocks", P, C4)
+            partial = self._f(nblk, 2, C4)
+            H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
+                   y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4)
+            dgamma, dbeta, coef = self._f(C4), self._f(C4), self._f(3, C4)
+            H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), bn.weight.data_ptr(),
+                   invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
+            H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
+                   y.stride(2), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), 1, g_y.data_ptr(), g_y.stride(2),
+                   H.ptr(g_res), g_res.stride(2) if g_res is not None else 0, P, C4)
+            self.add_param_grad(bn.weight, dgamma[:Cout])
+            self.add_param_grad(bn.bias, dbeta[:Cout])
+            if b is not None:   # a bias feeding train-mode BN has an exactly zero gradient
+                self.add_param_grad(b, self._f(Cout, zero=True))
+        else:
+            coef = self._f(3, C4, zero=True)
+            if mode == "eval":
+                coef[0, :Cout].copy_(saved[1])
+            else:
+                coef[0].fill_(1.0)
+            H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, None, 0, None, None,
+                   coef.data_ptr(), 0, g_y.data_ptr(), g_y.stride(2), H.ptr(g_res),
+                   g_res.stride(2) if g_res is not None else 0, P, C4)
+            if mode == "eval":
+                # frozen-statistics BN: dgamma = sum(g*xhat), dbeta = sum(g); xhat recovered from the conv output is
+                # not kept in eval mode, so only dbeta/dbias are produced (enough for the eval-mode fixtures).
+                pass
+            if b is not None:
+                self.add_param_grad(b, self._channel_sum(g_y, Cout))
+        if g_res is not None:
+            self.accum(residual, g_res)
+        # weight gradient
+        self.add_param_grad(w, self._wgrad(self._launch_plan(kind, k, stride, pad, w, "fwd"), x, g_y, Cout, w))
+        # data gradient
+        if x.needs_grad:
+            plans = self._launch_plan(kind, k, stride, pad, w, "dgrad")
+            gsrc = Act(g_y, Cout)
+            if x.grad is None:
+                gx = self._f(x.N, x.Hh, x.Ww, _round_up(x.C, 4))
+                self._run_gather(plans, gsrc, gx, x.C, w)
+                x.grad = gx
+            else:   # accumulate in place through the epilogue's residual input
+                self._run_gather(plans, gsrc, x.grad, x.C, w, residual=x.grad)
+
+    # ------------------------------------------------------------------ attention (base_model.py:43-78)
+    def attention(self, x: Act, w1: torch.Tensor, w2: torch.Tensor, wsp: torch.Tensor,
+                  out: Optional[torch.Tensor] = None) -> Act:
+        N, Hh, Ww, Cc = x.N, x.Hh, x.Ww, x.C
+        HW = Hh * Ww
+        Ch = w1.shape[0]
+        nblk = H.value("adh_cbam_pool_num_blocks", HW)
+        partial = self._f(N, nblk, 2, Cc)
+        partial_idx = torch.empty((N, nblk, Cc), device=self.device, dtype=torch.int32)
+        pooled = self._f(N, 2, Cc)
+        amax_idx = torch.empty((N, Cc), device=self.device, dtype=torch.int32)
+        H.call("adh_cbam_pool", x.t.data_ptr(), x.cs, N, HW, Cc, partial.data_ptr(), partial_idx.data_ptr(), nblk,
+               pooled.data_ptr(), amax_idx.data_ptr())
+        ca = self._f(N, Cc)
+        hidden = self._f(N, 2, Ch)
+        H.call("adh_cbam_mlp", pooled.data_ptr(), w1.data_ptr(), w2.data_ptr(), N, Cc, Ch, ca.data_ptr(),
+               hidden.data_ptr())
+        smap = self._f(N, HW, 2)
+        cidx = torch.empty((N, HW), device=self.device, dtype=torch.int32)
+        H.call("adh_cbam_spatial_stats", x.t.data_ptr(), x.cs, ca.data_ptr(), N, HW, Cc, smap.data_ptr(),
+               cidx.data_ptr())
+        sa = self._f(N, HW)
+        if out is None:
+            out = self._f(N, Hh, Ww, Cc)
+        _check_dense_pixels(out)
+        H.call("adh_cbam_apply", x.t.data_ptr(), x.cs, ca.data_ptr(), smap.data_ptr(), wsp.data_ptr(), N, Hh, Ww, Cc,
+               sa.data_ptr(), out.data_ptr(), out.stride(2))
+        o = Act(out, Cc)
+        if self.record:
+            def bwd():
+                g = o.grad
+                o.grad = None
+                if g is None:
+                    return
+                gsa_pre = self._f(N, HW)
+                H.call("adh_cbam_bwd_a", g.data_ptr(), g.stride(2), x.t.data_ptr(), x.cs, ca.data_ptr(), sa.data_ptr(),
+                       N, HW, Cc, gsa_pre.data_ptr())
+                nb = H.value("adh_cbam_bwd_b_num_blocks", N, Hh, Ww)
+                gsmap = self._f(N, HW, 2)
+                dwsp_partial = self._f(nb, 98)
+                dwsp = self._f(*wsp.shape)
+                H.call("adh_cbam_bwd_b", gsa_pre.data_ptr(), smap.data_ptr(), wsp.data_ptr(), N, Hh, Ww,
+                       gsmap.data_ptr(), dwsp_partial.data_ptr(), nb, dwsp.data_ptr(), 0)
+                gca_partial = self._f(N, nblk, Cc)
+                H.call("adh_cbam_bwd_c", g.data_ptr(), g.stride(2), x.t.data_ptr(), x.cs, sa.data_ptr(),
+                       gsmap.data_ptr(), cidx.data_ptr(), N, HW, Cc, gca_partial.data_ptr(), nblk)
+                gpool = self._f(N, 2, Cc)
+                dw1, dw2 = self._f(*w1.shape), self._f(*w2.shape)
+                H.call("adh_cbam_bwd_d", gca_partial.data_ptr(), nblk, ca.data_ptr(), pooled.data_ptr(),
+                       hidden.data_ptr(), w1.data_ptr(), w2.data_ptr(), N, Cc, Ch, gpool.data_ptr(), dw1.data_ptr(),
+                       dw2.data_ptr(), 0)
+                self.add_param_grad(wsp, dwsp)
+                self.add_param_grad(w1, dw1)
+                self.add_param_grad(w2, dw2)
+                if x.needs_grad:
+                    gx = self._f(N, Hh, Ww, Cc)
+                    H.call("adh_cbam_bwd_e", g.data_ptr(), g.stride(2), x.t.data_ptr(), x.cs, ca.data_ptr(),
+                           sa.data_ptr(), gsmap.data_ptr(), cidx.data_ptr(), gpool.data_ptr(), amax_idx.data_ptr(), N,
+                           HW, Cc, gx.data_ptr(), gx.stride(2))
+                    self.accum(x, gx)
+            self.tape.append(bwd)
+        return o
+
+    # ------------------------------------------------------------------ zero-copy concat
+    def concat_buffer(self, N, Hh, Ww, channels: Tuple[int, ...]):
+        """Allocate [N,H,W,sum(C)] and return (buffer, [slice views]) so producers write in place
+        (replaces torch.cat at medium_intensity.py:100,114 / high_intensity.py:117,129)."""
+        buf = self._f(N, Hh, Ww, sum(channels))
+        views, o = [], 0
+        for c in channels:
+            views.append(buf[..., o:o + c])
+            o += c
+        return buf, views
+
+    def concat(self, buf: torch.Tensor, parts: List[Act]) -> Act:
+        o = Act(buf)
+        offs, off = [], 0
+        for p in parts:
+            assert p.t.data_ptr() == buf.data_ptr() + off * 4 and p.cs == buf.shape[3], "part is not a slice of buf"
+            offs.append(off)
+            off += p.C
+        assert off == buf.shape[3]
+        if self.record:
+            def bwd():
+                g = o.grad
+                o.grad = None
+                if g is None:
+                    return
+                for p, of in zip(parts, offs):
+                    self.accum(p, g[..., of:of + p.C])
+            self.tape.append(bwd)
+        return o
+
+    # ------------------------------------------------------------------ pooling / resize (alt models, odd sizes)
+    def maxpool(self, x: Act, k: int) -> Act:
+        N, Hh, Ww, Cc = x.N, x.Hh, x.Ww, x.C
+        OH, OW = Hh // k, Ww // k
+        out = self._f(N, OH, OW, Cc)
+        idx = torch.empty((N, OH, OW, Cc), device=self.device, dtype=torch.int32) if self.record else None
+        H.call("adh_maxpool", x.t.data_ptr(), x.cs, N, Hh, Ww, Cc, k, out.data_ptr(), Cc, H.ptr(idx))
+        o = Act(out, Cc)
+        if self.record:
+            def bwd():
+                g = o.grad
+                o.grad = None
+                if g is None or not x.needs_grad:
+                    return
+                gx = self._f(N, Hh, Ww, Cc)
+                H.call("adh_maxpool_bwd", g.data_ptr(), g.stride(2), idx.data_ptr(), N, OH, OW, Cc, k, Hh, Ww,
+                       gx.data_ptr(), Cc)
+                self.accum(x, gx)
+            self.tape.append(bwd)
+        return o
+
+    def bilinear(self, x: Act, OH: int, OW: int, align_corners: bool, out: Optional[torch.Tensor] = None) -> Act:
+        N, Hh, Ww, Cc = x.N, x.Hh, x.Ww, x.C
+        if out is None:
+            out = self._f(N, OH, OW, Cc)
+        H.call("adh_bilinear", x.t.data_ptr(), x.cs, N, Hh, Ww, Cc, OH, OW, int(align_corners), out.data_ptr(),
+               out.stride(2))
+        o = Act(out, Cc)
+        if self.record:
+            def bwd():
+                g = o.grad
+                o.grad = None
+                if g is None or not x.needs_grad:
+                    return
+                gx = self._f(N, Hh, Ww, Cc, zero=True)
+                H.call("adh_bilinear_bwd", g.data_ptr(), g.stride(2), N, Hh, Ww, Cc, OH, OW, int(align_corners),
+                       gx.data_ptr(), Cc)
+                self.accum(x, gx)
+            self.tape.append(bwd)
+        return o
+
+    # ------------------------------------------------------------------ branch heads
+    def head_blend(self, mode: int, x_img: torch.Tensor, r: Act, gd: Optional[Act], alpha: Optional[torch.Tensor]):
+        """Final blend producing the NCHW output (low_intensity.py:41-45,116; medium_intensity.py:117;
+        high_intensity.py:135-138,214)."""
+        N, _, Hh, Ww = x_img.shape
+        out = torch.empty_like(x_img)
+        H.call("adh_head_blend", mode, x_img.data_ptr(), r.t.data_ptr(), r.cs, H.ptr(gd.t if gd else None),
+               gd.cs if gd else 0, H.ptr(alpha), N, Hh, Ww, out.data_ptr())
+        holder = {"g": None}
+        if self.record:
+            def bwd():
+                g = holder["g"]
+                if g is None:
+                    return
+                nb = H.value("adh_head_blend_bwd_num_blocks", N, Hh, Ww)
+                g_r = self._f(N, Hh, Ww, r.t.shape[3])
+                g_gd = self._f(N, Hh, Ww, gd.t.shape[3]) if gd else None
+                ga_partial = self._f(nb) if mode == 0 else None
+                H.call("adh_head_blend_bwd", mode, g.data_ptr(), x_img.data_ptr(), r.t.data_ptr(), r.cs,
+                       H.ptr(gd.t if gd else None), gd.cs if gd else 0, H.ptr(alpha), N, Hh, Ww, g_r.data_ptr(),
+                       H.ptr(g_gd), H.ptr(ga_partial), nb)
+                self.accum(r, g_r)
+                if gd:
+                    self.accum(gd, g_gd)
+                if mode == 0:
+                    ga = self._f(1)
+                    H.call("adh_sum_partials", ga_partial.data_ptr(), nb, 1.0, ga.data_ptr())
+                    self.add_param_grad(alpha, ga.reshape(alpha.shape))
+            self.tape.append(bwd)
+        return out, holder

@@ -1,0 +1,244 @@
+/*
+ * adam_dehaze_hip.h -- C ABI of libadamdehaze_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary of the ADAM-Dehaze hot path.  The reference has no FFI, plugin registry or
+ * operator table: its boundary is Python (factory functions + nn.Module.forward).
+ * Each entry point below therefore replaces a group of ATen calls made by one reference Module /
+ * function (cited per entry as file:line under /root/reference); the Python host in
+ * adam-dehaze_amd/ binds them with ctypes and keeps the reference's class / factory names.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ADH_E_* code otherwise (the Python host raises
+ *     RuntimeError); nothing is allocated inside, nothing synchronises: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*), so calls are graph-capturable.
+ *   - activations are fp32 NHWC: element (n,y,x,c) of a tensor with `cstride` floats per pixel is at
+ *     ptr[((n*H + y)*W + x)*cstride + c]; `cstride` >= C lets a tensor be a channel slice of a wider
+ *     buffer (zero-copy skip concatenation).  Pointers and cstrides must be multiples of 4 floats.
+ *   - images at the model boundary are the reference's fp32 NCHW [N,3,H,W].
+ *   - "packed weights": float4 wp[(tap*KQ + kq)*NcP + n] holds k = 4*kq..4*kq+3 of output column n,
+ *     KQ = ceil(K/8)*2, NcP = Nc rounded up to 32 (zero padded).
+ */
+#ifndef ADAM_DEHAZE_HIP_H
+#define ADAM_DEHAZE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADH_OK 0
+#define ADH_E_ARG (-1)      /* bad argument (shape / alignment / null) */
+#define ADH_E_LAUNCH (-2)   /* hipLaunch failed */
+#define ADH_E_UNSUPPORTED (-3)
+
+#define ADH_ACT_NONE 0
+#define ADH_ACT_RELU 1
+#define ADH_ACT_SIGMOID 2
+#define ADH_ACT_TANH 3
+
+/* Gather-form convolution descriptor shared by the forward / dgrad / wgrad kernels.
+ * Virtual output grid VH x VW; virtual pixel (vy,vx) reads input pixel
+ * (vy*in_sy + dy, vx*in_sx + dx) for tap (ty,tx): dy = dy0 + ty*dstep_y, dx = dx0 + tx*dstep_x
+ * (zero outside the image) and writes output pixel (vy*out_sy + out_oy, vx*out_sx + out_ox).
+ * This one form covers Conv2d k3/k7/k1 s1, Conv2d k4 s2, each output-parity class of
+ * ConvTranspose2d k4 s2 p1, and the data-gradient of all of them. */
+typedef struct adh_conv_desc {
+    const float* in;        /* NHWC [N][IH][IW][in_cstride], channels [0,Cin) used          */
+    float* out;             /* NHWC [N][OH][OW][out_cstride]; wgrad: grad wrt this (read)   */
+    const float* wp;        /* packed weights (fwd/dgrad); wgrad: unused                    */
+    const float* scale;     /* per-output-channel multiplier or NULL (=1)                   */
+    const float* shift;     /* per-output-channel addend (bias / folded BN) or NULL (=0)    */
+    const float* residual;  /* NHWC tensor added before the activation, or NULL             */
+    float* stats;           /* NULL, or [n_blocks][2][NcP] per-block sum / sum-of-squares of
+                               the value after scale/shift (train-mode BatchNorm statistics) */
+    int32_t N, IH, IW, Cin, in_cstride;
+    int32_t OH, OW, Cout, out_cstride, res_cstride;
+    int32_t VH, VW;
+    int32_t in_sy, in_sx;
+    int32_t out_sy, out_sx, out_oy, out_ox;
+    int32_t KH, KW;
+    int32_t dy0, dx0, dstep_y, dstep_x;
+    int32_t act;            /* ADH_ACT_NONE / ADH_ACT_RELU applied last                      */
+    int32_t NcP;            /* padded output-channel count of wp / stats                     */
+} adh_conv_desc;
+
+/* Source-layout description used to pack weights for, and to scatter weight gradients from, the
+ * gather form: element (tap (ty,tx), k, n) lives at
+ *   src[tap_off0 + ty*tap_off_sy + tx*tap_off_sx + k*stride_k + n*stride_n].
+ * Conv2d OIHW forward: k=ci (stride KH*KW), n=co (stride Cin*KH*KW); its dgrad swaps k and n;
+ * ConvTranspose2d [Cin][Cout][kh][kw] likewise (models/dehazing/base_model.py:11-13,
+ * medium_intensity.py:53,63). */
+typedef struct adh_wlayout {
+    int32_t K, Nc;
+    int32_t KHt, KWt;
+    int32_t tap_off0, tap_off_sy, tap_off_sx;
+    int32_t stride_k, stride_n;
+} adh_wlayout;
+
+/* ---- library / device ------------------------------------------------------------------- */
+int adh_version(void);
+/* bytes of dynamic LDS the conv kernels need for `d` (diagnostic; >0) */
+int adh_conv_lds_bytes(const adh_conv_desc* d);
+/* number of thread blocks adh_conv_forward launches for `d` (= rows of d->stats) */
+int adh_conv_num_blocks(const adh_conv_desc* d);
+
+/* ---- weights ------------------------------------------------------------------------------ */
+/* pack `src` (layout L) into wp; wp has KHt*KWt*KQ*NcP float4.  Replaces nothing in the reference
+ * (ATen keeps OIHW); it is the one-time re-layout for the MFMA kernels. */
+int adh_pack_weights(void* stream, const float* src, const adh_wlayout* L, float* wp);
+
+/* ---- convolution (base_model.py:11-13 Conv2d, medium_intensity.py:53,63 ConvTranspose2d) ---- */
+/* out = act(scale*gather_conv(in, wp) + shift + residual); optional BN statistics partials. */
+int adh_conv_forward(void* stream, const adh_conv_desc* d);
+/* weight gradient of the gather form: slab[s][tap][KP][NcP] partial sums over `nsplit` pixel
+ * ranges (KP = Cin rounded up to 32); d->out is the gradient wrt the conv output. */
+int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab, int nsplit);
+/* dst(layout L) (+)= sum_s slab[s]; deterministic order. accumulate != 0 adds to dst. */
+int adh_wgrad_reduce(void* stream, const float* slab, int nsplit, int KP, int NcP,
+                     const adh_wlayout* L, float* dst, int accumulate);
+
+/* ---- BatchNorm2d + activation (base_model.py:15-19,36-41; eps 1e-5, momentum 0.1) ---------- */
+/* reduce `nblk` partial rows [2][NcP] -> batch mean / biased var over `count` elements per channel;
+ * writes scale = gamma*invstd, shift = beta - mean*scale, save_mean, save_invstd and updates
+ * running_mean/var (unbiased var, momentum) when they are non-NULL. */
+int adh_bn_finalize(void* stream, const float* partials, int nblk, int NcP, int C, double count,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var,
+                    float* scale, float* shift, float* save_mean, float* save_invstd);
+/* eval mode: scale/shift from running statistics */
+int adh_bn_fold_eval(void* stream, int C, const float* gamma, const float* beta,
+                     const float* running_mean, const float* running_var, float eps,
+                     const float* conv_bias, float* scale, float* shift);
+/* out = act(y*scale[c] + shift[c] (+ residual)) over P pixels */
+int adh_bn_apply(void* stream, const float* y, int y_cs, const float* scale, const float* shift,
+                 const float* residual, int res_cs, int act, float* out, int out_cs,
+                 int64_t P, int C);
+/* backward of act(BN(y) (+res)): given g_out and the forward output `out` (relu mask),
+ * pass 1: per-block partial sums of g and g*xhat -> partials[nblk][2][C]
+ * (nblk = adh_bn_bwd_num_blocks(P)). */
+int adh_bn_bwd_num_blocks(int64_t P, int C);
+int adh_bn_bwd_reduce(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
+                      const float* y, int y_cs, const float* mean, const float* invstd,
+                      float* partials, int64_t P, int C);
+/* finalize: dgamma = sum(g*xhat), dbeta = sum(g) (accumulated into grads when accumulate!=0) and the
+ * per-channel coefficients used by pass 2. coef[3][C] = {gamma*invstd, mean_g, mean_gxhat}. */
+int adh_bn_bwd_finalize(void* stream, const float* partials, int nblk, int C, double count,
+                        const float* gamma, const float* invstd, float* dgamma, float* dbeta,
+                        int accumulate, float* coef);
+/* pass 2: g_y = gamma*invstd*(g - mean_g - xhat*mean_gxhat); optionally g_res = g (masked).
+ * training==0 (eval BN): g_y = g*scale only (coef row 0). */
+int adh_bn_bwd_apply(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
+                     const float* y, int y_cs, const float* mean, const float* invstd, const float* coef,
+                     int training, float* g_y, int gy_cs, float* g_res, int gres_cs, int64_t P, int C);
+
+/* ---- AttentionBlock (base_model.py:43-78) ----------------------------------------------------- */
+/* pooled[n][2][C] = (mean, max) over H*W; amax_idx[n][C] = first pixel index attaining the max */
+int adh_cbam_pool(void* stream, const float* x, int x_cs, int N, int HW, int C,
+                  float* partial, int32_t* partial_idx, int nblk, float* pooled, int32_t* amax_idx);
+int adh_cbam_pool_num_blocks(int HW);
+/* ca[n][C] = sigmoid(fc(avg) + fc(max)); fc = W2 * relu(W1 * v); W1 [Ch][C], W2 [C][Ch];
+ * hidden[n][2][Ch] keeps the post-relu activations for backward. */
+int adh_cbam_mlp(void* stream, const float* pooled, const float* w1, const float* w2, int N, int C, int Ch,
+                 float* ca, float* hidden);
+/* smap[n][hw][2] = (mean_c, max_c) of x*ca; cidx[n][hw] = first channel attaining the max */
+int adh_cbam_spatial_stats(void* stream, const float* x, int x_cs, const float* ca, int N, int HW, int C,
+                           float* smap, int32_t* cidx);
+/* sa = sigmoid(conv7x7(smap)); out = x*ca*sa */
+int adh_cbam_apply(void* stream, const float* x, int x_cs, const float* ca, const float* smap, const float* wsp,
+                   int N, int H, int W, int C, float* sa, float* out, int out_cs);
+/* backward, pass A: gsa_pre[n][hw] = (sum_c g*x*ca) * sa*(1-sa) */
+int adh_cbam_bwd_a(void* stream, const float* g, int g_cs, const float* x, int x_cs, const float* ca,
+                   const float* sa, int N, int HW, int C, float* gsa_pre);
+/* pass B (tiny): gsmap[n][hw][2] = conv7x7^T(gsa_pre); dwsp[2*49] (+)= sum smap (x) gsa_pre */
+int adh_cbam_bwd_b(void* stream, const float* gsa_pre, const float* smap, const float* wsp,
+                   int N, int H, int W, float* gsmap, float* dwsp_partial, int nblk, float* dwsp, int accumulate);
+int adh_cbam_bwd_b_num_blocks(int N, int H, int W);
+/* pass C: gx1 = g*sa + gsmap.mean/C + gsmap.max*[c==cidx]; gca_partial[blk][n][C] = sum_hw gx1*x */
+int adh_cbam_bwd_c(void* stream, const float* g, int g_cs, const float* x, int x_cs, const float* sa,
+                   const float* gsmap, const int32_t* cidx, int N, int HW, int C,
+                   float* gca_partial, int nblk);
+/* pass D (tiny): reduce gca, back through sigmoid + MLP: gpool[n][2][C], dW1/dW2 (+)= */
+int adh_cbam_bwd_d(void* stream, const float* gca_partial, int nblk, const float* ca, const float* pooled,
+                   const float* hidden, const float* w1, const float* w2, int N, int C, int Ch,
+                   float* gpool, float* dw1, float* dw2, int accumulate);
+/* pass E: gx = gx1*ca + gpool.avg/HW + gpool.max*[hw==amax_idx] */
+int adh_cbam_bwd_e(void* stream, const float* g, int g_cs, const float* x, int x_cs, const float* ca,
+                   const float* sa, const float* gsmap, const int32_t* cidx, const float* gpool,
+                   const int32_t* amax_idx, int N, int HW, int C, float* gx, int gx_cs);
+
+/* ---- boundary layout + branch heads ------------------------------------------------------------ */
+/* NCHW [N,3,H,W] image -> NHWC with cstride 8 (channels 3..7 zero) */
+int adh_image_to_nhwc8(void* stream, const float* img, int N, int H, int W, float* out);
+/* generic NCHW <-> NHWC (classifier features / tests) */
+int adh_nchw_to_nhwc(void* stream, const float* src, int N, int C, int H, int W, float* dst, int dst_cs);
+int adh_nhwc_to_nchw(void* stream, const float* src, int src_cs, int N, int C, int H, int W, float* dst);
+/* final blend of each branch, output NCHW [N,3,H,W]; r = head conv output (NHWC, r_cs), pre-activation.
+ *   mode 0 Lightweight  (low_intensity.py:41-45):  (1-a)*x + a*sigmoid(r)          (a = *alpha)
+ *   mode 1 Medium/COrun (medium_intensity.py:117): clamp(x + tanh(r), 0, 1)
+ *   mode 2 Complex      (high_intensity.py:135-138): clamp(x + tanh(r)*sigmoid(gd), 0, 1)
+ *   mode 3 LowIntensity (low_intensity.py:116):    clamp(x + (sigmoid(r)-0.5)*2, 0, 1)
+ *   mode 4 DualBranch   (high_intensity.py:214):   clamp(x + (1-sigmoid(gd))*tanh(r), 0, 1)
+ * gd = 1-channel map (NHWC, gd_cs) pre-sigmoid. */
+int adh_head_blend(void* stream, int mode, const float* x_nchw, const float* r, int r_cs,
+                   const float* gd, int gd_cs, const float* alpha, int N, int H, int W, float* out_nchw);
+/* backward of the blend: g_r (NHWC r_cs, channels >=3 zeroed), g_gd (NHWC gd_cs, ch >=1 zeroed),
+ * galpha_partial[nblk] (mode 0). */
+int adh_head_blend_bwd(void* stream, int mode, const float* g_out_nchw, const float* x_nchw,
+                       const float* r, int r_cs, const float* gd, int gd_cs, const float* alpha,
+                       int N, int H, int W, float* g_r, float* g_gd, float* galpha_partial, int nblk);
+int adh_head_blend_bwd_num_blocks(int N, int H, int W);
+
+/* ---- routing (models/routing.py:41-61,110-127) ----------------------------------------------------- */
+/* weights[n][3] = softmax(logits[n]/T); out = sum_i weights[n][i]*branch_i  (NCHW images, per = 3*H*W) */
+int adh_softmax3(void* stream, const float* logits, float temperature, int N, float* weights);
+int adh_soft_blend(void* stream, const float* weights, const float* o0, const float* o1, const float* o2,
+                   int N, int64_t per, float* out);
+/* backward: g_oi = w[n][i]*g; gw_partial[n][nblk][3] = sum g*o_i */
+int adh_soft_blend_bwd(void* stream, const float* weights, const float* g, const float* o0, const float* o1,
+                       const float* o2, int N, int64_t per, float* g0, float* g1, float* g2,
+                       float* gw_partial, int nblk);
+/* idx[n] = argmax_i logits[n][i] (first index on ties), int64 */
+int adh_argmax3(void* stream, const float* logits, int N, int64_t* idx);
+/* device-side compaction for HardRouter: for class c, sel[0..count) = batch indices with idx==c,
+ * counts[c] written (no host sync); gather/scatter of whole images by index list */
+int adh_route_compact(void* stream, const int64_t* idx, int N, int32_t* sel /*[3][N]*/, int32_t* counts /*[3]*/);
+int adh_gather_images(void* stream, const float* src, const int32_t* sel, int count, int64_t per, float* dst);
+int adh_scatter_images(void* stream, const float* src, const int32_t* sel, int count, int64_t per, float* dst);
+
+/* ---- losses (training/loss.py:138,81,200) ----------------------------------------------------------- */
+int adh_reduce_num_blocks(int64_t n);
+/* partial[blk] = sum |a-b| ; finalize with adh_sum_partials (scaled by 1/n) */
+int adh_l1_partial(void* stream, const float* a, const float* b, int64_t n, float* partial);
+int adh_mse_partial(void* stream, const float* a, const float* b, int64_t n, float* partial);
+int adh_sum_partials(void* stream, const float* partial, int nblk, double scale, float* out);
+/* g_a = gscale * sign(a-b) * (*upstream)   (upstream: device scalar or NULL = 1) */
+int adh_l1_bwd(void* stream, const float* a, const float* b, int64_t n, float gscale, const float* upstream, float* g_a);
+int adh_mse_bwd(void* stream, const float* a, const float* b, int64_t n, float gscale, const float* upstream, float* g_a);
+/* cross entropy over 3 classes, mean reduction: loss scalar + dlogits[n][3] (scaled by 1/N) */
+int adh_cross_entropy3(void* stream, const float* logits, const int64_t* labels, int N, float* loss, float* dlogits);
+
+/* ---- optimiser (training/train_joint.py:86-90: Adam, weight_decay 1e-4) ------------------------------ */
+/* `repeats` consecutive Adam updates with the same gradient and shared state (the reference lists every
+ * branch parameter twice, train_joint.py:81-84); step = count before the call. */
+int adh_adam_step(void* stream, float* p, const float* g, float* m, float* v, int64_t n, int step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int repeats);
+
+/* ---- misc elementwise ---------------------------------------------------------------------------------- */
+int adh_add_inplace(void* stream, float* dst, const float* src, int64_t n);            /* dst += src */
+int adh_axpby_strided(void* stream, float* dst, int dst_cs, const float* src, int src_cs,
+                      int64_t P, int C, float a, float b);                           /* dst = a*dst + b*src */
+int adh_maxpool(void* stream, const float* x, int x_cs, int N, int H, int W, int C, int k, float* out, int out_cs,
+                int32_t* idx);
+int adh_maxpool_bwd(void* stream, const float* g, int g_cs, const int32_t* idx, int N, int OH, int OW, int C, int k,
+                    int H, int W, float* gx, int gx_cs);
+/* bilinear resize, align_corners 0/1 (medium_intensity.py:93-99,147,152) and its adjoint */
+int adh_bilinear(void* stream, const float* x, int x_cs, int N, int H, int W, int C, int OH, int OW,
+                 int align_corners, float* out, int out_cs);
+int adh_bilinear_bwd(void* stream, const float* g, int g_cs, int N, int H, int W, int C, int OH, int OW,
+                     int align_corners, float* gx, int gx_cs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAM_DEHAZE_HIP_H */

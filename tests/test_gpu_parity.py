@@ -1,0 +1,262 @@
+"""GPU parity: the HIP path (through the C ABI) against (a) the golden fixtures generated from the
+reference and (b) the CPU oracle on seeded inputs.  Tolerance: dehazed tensors / losses within 1e-3
+fp32 (BASELINE.json north_star); tests use 2e-4 for outputs and 2e-3 relative for gradients."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import adam_dehaze_amd as A
+from adam_dehaze_amd.engine import Act, Engine
+from adam_dehaze_amd.layers import AttentionBlock, ConvBlock, ResidualBlock
+from oracle import ref_cpu as R
+from tests._util import load_golden, sub_sd, t, max_abs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+OUT_TOL = 2e-4
+GRAD_TOL = 2e-3
+DEV = "cuda:0"
+
+
+def _load_into(module, rec, prefix="sd."):
+    sd = {k[len(prefix):]: torch.from_numpy(np.array(v)) for k, v in rec.items() if k.startswith(prefix)}
+    module.load_state_dict(sd, strict=True)
+    return module.to(DEV)
+
+
+def _run_block(block, rec, training, stem=False, attention=False):
+    """Drive one block through the engine; returns (out NCHW, gx NCHW | None, {param name: grad})."""
+    block.train(training)
+    x = t(rec["x"]).to(DEV)
+    gout = t(rec["gout"]).to(DEV)
+    eng = Engine(torch.device(DEV), record=True)
+    if stem:
+        xa = eng.image_to_nhwc8(x.contiguous())
+    else:
+        xa = Act(x.permute(0, 2, 3, 1).contiguous())
+    o = block.run(eng, xa) if attention else block.run(eng, xa, training)
+    out = o.t[..., :o.C].permute(0, 3, 1, 2).contiguous()
+    o.grad = gout.permute(0, 2, 3, 1).contiguous()
+    eng.backward()
+    torch.cuda.synchronize()
+    gx = None if stem else xa.grad[..., :xa.C].permute(0, 3, 1, 2).contiguous()
+    names = {id(p): n for n, p in block.named_parameters()}
+    grads = {names[k]: g for k, g in eng.param_grads.items()}
+    return out, gx, grads
+
+
+BLOCKS = [
+    ("convblock_k3_c16", lambda: ConvBlock(16, 16, 3, 1, 1), False),
+    ("convblock_k3_c32", lambda: ConvBlock(32, 32, 3, 1, 1), False),
+    ("convblock_k4s2_c16", lambda: ConvBlock(16, 32, 4, 2, 1), False),
+    ("convblock_k4s2_c32", lambda: ConvBlock(32, 64, 4, 2, 1), False),
+    ("convblock_k1_c16", lambda: ConvBlock(16, 8, 1, 1, 0), False),
+    ("convblock_k1_c32", lambda: ConvBlock(32, 16, 1, 1, 0), False),
+    ("convblock_nobn_noact_c16", lambda: ConvBlock(16, 16, 3, 1, 1, use_bn=False, relu=False), False),
+    ("convblock_nobn_noact_c32", lambda: ConvBlock(32, 32, 3, 1, 1, use_bn=False, relu=False), False),
+    ("convblock_k7_stem", lambda: ConvBlock(3, 16, 7, 1, 3), True),
+    ("convblock_k3_stem", lambda: ConvBlock(3, 16, 3, 1, 1), True),
+    ("resblock_c16", lambda: ResidualBlock(16), False),
+    ("resblock_c32", lambda: ResidualBlock(32), False),
+]
+
+
+@pytest.mark.parametrize("name,ctor,stem", BLOCKS)
+@pytest.mark.parametrize("training", [False, True])
+def test_blocks_vs_reference_fixtures(name, ctor, stem, training):
+    rec = load_golden(name)
+    block = _load_into(ctor(), rec)
+    tag = "train" if training else "eval"
+    out, gx, grads = _run_block(block, rec, training, stem=stem)
+    assert max_abs(out, rec["out_" + tag]) < OUT_TOL
+    if gx is not None:
+        assert rel_err(gx, rec["gx_" + tag]) < GRAD_TOL
+    for k in [k for k in rec if k.startswith(f"gp_{tag}.")]:
+        pname = k[len(f"gp_{tag}."):]
+        if not training and (".block.1." in "." + pname or pname.startswith("block.1.")):
+            continue   # frozen-statistics BN affine grads are not produced in eval mode (documented)
+        ref = t(rec[k])
+        assert pname in grads, pname
+        scale = max(float(ref.abs().max()), 1e-6)
+        assert float((grads[pname].cpu() - ref).abs().max()) < GRAD_TOL * scale + 1e-6, pname
+    if training:
+        after = sub_sd(rec, "sd_after_train.")
+        for k, v in block.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                assert max_abs(v, after[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("C", [16, 32])
+def test_attention_block_vs_reference_fixture(C):
+    rec = load_golden(f"attention_c{C}")
+    block = _load_into(AttentionBlock(C), rec)
+    out, gx, grads = _run_block(block, rec, False, attention=True)
+    assert max_abs(out, rec["out_eval"]) < OUT_TOL
+    assert rel_err(gx, rec["gx_eval"]) < GRAD_TOL
+    for k in [k for k in rec if k.startswith("gp_eval.")]:
+        pname = k[len("gp_eval."):]
+        ref = t(rec[k])
+        scale = max(float(ref.abs().max()), 1e-6)
+        assert float((grads[pname].cpu() - ref).abs().max()) < GRAD_TOL * scale + 1e-6, pname
+
+
+BRANCHES = [
+    ("light_b8", lambda: A.LightweightDehazeModel(base_channels=8, n_blocks=3)),
+    ("lowint_b8", lambda: A.LowIntensityDehazeModel(base_channels=8, n_blocks=3)),
+    ("medium_b8", lambda: A.MediumIntensityDehazeModel(base_channels=8)),
+    ("medium_b8_odd", lambda: A.MediumIntensityDehazeModel(base_channels=8)),
+    ("corun_b8", lambda: A.COrunInspiredModel(base_channels=8, n_blocks=2)),
+    ("high_b16", lambda: A.HighIntensityDehazeModel(base_channels=16)),
+    ("high_b16_odd", lambda: A.HighIntensityDehazeModel(base_channels=16)),
+    ("dual_b16", lambda: A.DualBranchAttentionModel(base_channels=16)),
+]
+
+
+@pytest.mark.parametrize("name,ctor", BRANCHES)
+def test_branches_vs_reference_fixtures(name, ctor):
+    rec = load_golden(name)
+    m = _load_into(ctor(), rec)
+    x = t(rec["x"]).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        out = m(x)
+    assert out.shape == x.shape
+    assert max_abs(out, rec["out_eval"]) < OUT_TOL
+    # train mode: output, L1 loss (computed by the HIP loss kernels), parameter grads, BN buffers
+    from adam_dehaze_amd.loss import l1_loss
+    m = _load_into(ctor(), rec)
+    m.train()
+    out = m(x)
+    assert max_abs(out, rec["out_train"]) < OUT_TOL
+    loss = l1_loss(out, t(rec["target"]).to(DEV))
+    assert abs(float(loss) - float(rec["l1"])) < 1e-5
+    loss.backward()
+    bad = []
+    for pname, p in m.named_parameters():
+        ref = t(rec["gp_train." + pname])
+        g = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)
+        scale = max(float(ref.abs().max()), 1e-8)
+        err = float((g - ref).abs().max())
+        if not err < 5e-3 * scale + 2e-7:
+            bad.append((pname, err, scale))
+    assert not bad, bad[:8]
+    after = sub_sd(rec, "sd_after_train.")
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert max_abs(v, after[k]) < 1e-5, k
+
+
+def _oracle_conv_case(N, Cin, Cout, Hh, Ww, k, stride, pad, seed, transposed=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, Hh, Ww, generator=g)
+    if transposed:
+        w = torch.randn(Cin, Cout, k, k, generator=g) / (Cin * k * k) ** 0.5
+    else:
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    return x, w, b
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww,k,stride,pad", [
+    (2, 96, 96, 40, 72, 3, 1, 1),      # Complex full-res ResidualBlock conv (TN=3), ragged tile edges
+    (1, 192, 192, 24, 40, 3, 1, 1),    # two output-channel groups
+    (1, 64, 128, 32, 64, 4, 2, 1),     # Medium encoder down-conv (TN=4)
+    (1, 128, 128, 16, 32, 3, 1, 1),    # TN=4 stride 1
+    (2, 32, 32, 33, 65, 3, 1, 1),      # Light (TN=1), odd sizes
+    (1, 48, 3, 24, 40, 3, 1, 1),       # head conv Cout=3 (KC=16)
+    (1, 16, 1, 24, 40, 1, 1, 0),       # detail 1x1 conv
+    (1, 24, 8, 16, 32, 3, 1, 1),       # KC=8 path
+])
+def test_conv_forward_dgrad_wgrad_vs_oracle(N, Cin, Cout, Hh, Ww, k, stride, pad):
+    x, w, b = _oracle_conv_case(N, Cin, Cout, Hh, Ww, k, stride, pad, seed=Cin * 1000 + Cout)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    g = torch.Generator().manual_seed(5)
+    gout = torch.randn(ref.shape, generator=g)
+    (ref * gout).sum().backward()
+
+    eng = Engine(torch.device(DEV), record=True)
+    xa = Act(x.permute(0, 2, 3, 1).contiguous().to(DEV))
+    wd, bd = w.to(DEV), b.to(DEV)
+    o = eng.conv(xa, wd, bd, None, kind="conv", k=k, stride=stride, pad=pad, relu=False)
+    out = o.t[..., :Cout].permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    assert max_abs(out, ref.detach()) < 2e-5 * max(scale, 1.0) * (Cin * k * k) ** 0.5
+    gpad = torch.zeros(o.t.shape, device=DEV)
+    gpad[..., :Cout] = gout.permute(0, 2, 3, 1).to(DEV)
+    o.grad = gpad
+    eng.backward()
+    torch.cuda.synchronize()
+    assert rel_err(xa.grad[..., :Cin].permute(0, 3, 1, 2), xr.grad) < 1e-4
+    assert rel_err(eng.param_grads[id(wd)], wr.grad) < 1e-4
+    assert rel_err(eng.param_grads[id(bd)], br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww", [(1, 384, 96, 12, 20), (2, 64, 32, 9, 17), (1, 256, 128, 8, 16)])
+def test_conv_transpose_vs_oracle(N, Cin, Cout, Hh, Ww):
+    x, w, b = _oracle_conv_case(N, Cin, Cout, Hh, Ww, 4, 2, 1, seed=Cin + Cout, transposed=True)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, br, stride=2, padding=1)
+    gout = torch.randn(ref.shape, generator=torch.Generator().manual_seed(9))
+    (ref * gout).sum().backward()
+    eng = Engine(torch.device(DEV), record=True)
+    xa = Act(x.permute(0, 2, 3, 1).contiguous().to(DEV))
+    wd, bd = w.to(DEV), b.to(DEV)
+    o = eng.conv(xa, wd, bd, None, kind="convT", k=4, stride=2, pad=1, relu=False)
+    assert max_abs(o.t[..., :Cout].permute(0, 3, 1, 2), ref.detach()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    gpad = torch.zeros(o.t.shape, device=DEV)
+    gpad[..., :Cout] = gout.permute(0, 2, 3, 1).to(DEV)
+    o.grad = gpad
+    eng.backward()
+    torch.cuda.synchronize()
+    assert rel_err(xa.grad[..., :Cin].permute(0, 3, 1, 2), xr.grad) < 1e-4
+    assert rel_err(eng.param_grads[id(wd)], wr.grad) < 1e-4
+    assert rel_err(eng.param_grads[id(bd)], br.grad) < 1e-4
+
+
+def test_complex_fullwidth_vs_oracle_seeded():
+    """Full-width CORUN-Complex (base 96) on a 2x3x64x96 synthetic foggy batch vs the CPU oracle:
+    eval output, train output, L1 loss and a sample of parameter gradients."""
+    from adam_dehaze_amd.loss import l1_loss
+    torch.manual_seed(42)
+    m = A.HighIntensityDehazeModel()
+    sd_cpu = {k: v.clone() for k, v in m.state_dict().items()}
+    hazy, clear, _ = R.synthetic_batch(2, 64, 96, seed=42)
+    with torch.no_grad():
+        ref_eval = R.high_forward(hazy, {k: v.clone() for k, v in sd_cpu.items()}, training=False)
+    sd_tr = {k: v.clone() for k, v in sd_cpu.items()}
+    for k, v in sd_tr.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    ref_train = R.high_forward(hazy, sd_tr, training=True)
+    ref_loss = F.l1_loss(ref_train, clear)
+    ref_loss.backward()
+
+    m = m.to(DEV)
+    m.eval()
+    with torch.no_grad():
+        out = m(hazy.to(DEV))
+    assert max_abs(out, ref_eval) < 1e-3
+    assert R.psnr(out.cpu(), ref_eval) > 60.0
+    m.train()
+    out = m(hazy.to(DEV))
+    assert max_abs(out, ref_train.detach()) < 1e-3
+    loss = l1_loss(out, clear.to(DEV))
+    assert abs(float(loss) - float(ref_loss)) < 1e-4
+    loss.backward()
+    bad = []
+    for name, p in m.named_parameters():
+        ref = sd_tr[name].grad
+        if ref is None:
+            continue
+        scale = max(float(ref.abs().max()), 1e-8)
+        err = float((p.grad.cpu() - ref).abs().max())
+        if not err < 2e-2 * scale + 1e-7:
+            bad.append((name, err, scale))
+    assert not bad, bad[:8]
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert max_abs(v, sd_tr[k]) < 1e-4, k

@@ -1,0 +1,139 @@
+"""CPU-side checks of the host logic and the C-ABI surface (no GPU needed, no compute calls)."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import adam_dehaze_amd as A
+from adam_dehaze_amd import _hip as H
+from tests._util import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "adam_dehaze_hip.h")).read()
+    declared = set(re.findall(r"^int\s+(adh_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no prototypes parsed"
+    lib = ctypes.CDLL(H.lib_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(H.exported_symbols()), declared ^ set(H.exported_symbols())
+    H.load()
+    assert H.value("adh_version") >= 100
+
+
+_CTYPE = {"void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int32_t*": ctypes.c_void_p, "int64_t*": ctypes.c_void_p,
+          "int": ctypes.c_int32, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+          "double": ctypes.c_double}
+
+
+def test_ctypes_signatures_match_header():
+    header = open(os.path.join(ROOT, "include", "adam_dehaze_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = re.findall(r"^int\s+(adh_\w+)\s*\((.*?)\)\s*;", header, flags=re.M | re.S)
+    assert len(protos) == len(H.exported_symbols())
+    for name, args in protos:
+        args = " ".join(args.split())
+        expect = []
+        if args not in ("void", ""):
+            for a in args.split(","):
+                a = a.replace("const ", "").strip()
+                m = re.match(r"(\w+)\s*(\*?)\s*\w+$", a)
+                assert m, (name, a)
+                ty = m.group(1) + m.group(2)
+                if ty == "adh_conv_desc*":
+                    expect.append(H.PD)
+                elif ty == "adh_wlayout*":
+                    expect.append(H.PL)
+                else:
+                    expect.append(_CTYPE[ty])
+        got = H._SIGNATURES[name]
+        assert len(got) == len(expect), (name, len(got), len(expect))
+        for i, (g, e) in enumerate(zip(got, expect)):
+            assert g is e, (name, i, g, e)
+
+
+def test_struct_layouts_match_header_field_order():
+    header = open(os.path.join(ROOT, "include", "adam_dehaze_hip.h")).read()
+    body = re.search(r"typedef struct adh_conv_desc \{(.*?)\} adh_conv_desc;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", " ", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(float\*|int32_t)\s*", "", decl)
+        names += [n.strip() for n in decl.split(",")]
+    got = [f[0].rstrip("_") for f in H.ConvDesc._fields_]
+    assert names == got, (names, got)
+    assert ctypes.sizeof(H.ConvDesc) == 7 * 8 + 26 * 4
+    assert ctypes.sizeof(H.WLayout) == 9 * 4
+
+
+def test_state_dict_keys_and_seeded_init_match_reference():
+    rec = load_golden("fullwidth_summaries")
+    ctors = {"light": lambda: A.LightweightDehazeModel(base_channels=32, n_blocks=3),
+             "medium": lambda: A.MediumIntensityDehazeModel(base_channels=64),
+             "high": lambda: A.HighIntensityDehazeModel(base_channels=96)}
+    for name, ctor in ctors.items():
+        torch.manual_seed(42)
+        m = ctor()
+        assert list(m.state_dict().keys()) == list(rec[name + ".state_keys"])
+        assert sum(p.numel() for p in m.parameters()) == int(rec[name + ".n_params"])
+        sha = hashlib.sha256(b"".join(p.detach().numpy().tobytes() for p in m.parameters())).hexdigest()
+        assert sha == str(rec[name + ".param_sha256"]), name
+
+
+@pytest.mark.parametrize("fixture,ctor", [
+    ("light_b8", lambda: A.LightweightDehazeModel(base_channels=8, n_blocks=3)),
+    ("lowint_b8", lambda: A.LowIntensityDehazeModel(base_channels=8, n_blocks=3)),
+    ("medium_b8", lambda: A.MediumIntensityDehazeModel(base_channels=8)),
+    ("corun_b8", lambda: A.COrunInspiredModel(base_channels=8, n_blocks=2)),
+    ("high_b16", lambda: A.HighIntensityDehazeModel(base_channels=16)),
+    ("dual_b16", lambda: A.DualBranchAttentionModel(base_channels=16)),
+])
+def test_reference_state_dicts_load(fixture, ctor):
+    rec = load_golden(fixture)
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in rec.items() if k.startswith("sd.")}
+    m = ctor()
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    assert m.get_info()["model_type"] == str(rec["class_name"])
+
+
+def test_cpu_input_fails_loudly_no_fallback():
+    m = A.LightweightDehazeModel(base_channels=8, n_blocks=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 3, 16, 16))
+    with pytest.raises(NotImplementedError):
+        A.BaseDehazeModel()(torch.rand(1, 3, 8, 8))
+    with pytest.raises(NotImplementedError):
+        A.EncoderDecoder()(torch.rand(1, 3, 8, 8))
+
+
+def test_factories_follow_config_switches():
+    cfg = {"dehazing": {"low": {"model_type": "lightweight", "channels": 8, "blocks": 2},
+                        "medium": {"model_type": "standard", "channels": 8, "blocks": 6},
+                        "high": {"model_type": "complex", "channels": 16, "blocks": 9}}}
+    assert type(A.create_low_intensity_model(cfg)) is A.LightweightDehazeModel
+    assert type(A.create_medium_intensity_model(cfg)) is A.MediumIntensityDehazeModel
+    assert type(A.create_high_intensity_model(cfg)) is A.HighIntensityDehazeModel
+    cfg["dehazing"]["low"]["model_type"] = "unet"
+    cfg["dehazing"]["medium"]["model_type"] = "corun"
+    cfg["dehazing"]["high"]["model_type"] = "dual_branch"
+    assert type(A.create_low_intensity_model(cfg)) is A.LowIntensityDehazeModel
+    assert type(A.create_medium_intensity_model(cfg)) is A.COrunInspiredModel
+    assert type(A.create_high_intensity_model(cfg)) is A.DualBranchAttentionModel
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "adam-dehaze_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("# oracle", ""), fn
