@@ -145,9 +145,40 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def call(name: str, *args):
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events recorded on the launch stream (bench.py's
+    roofline leg).  `work` is the algorithmic FLOP (or byte) count of the launch."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []   # (name, start_event, end_event, work)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, e0, e1, work in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += work
+        return {k: {"launches": v[0], "seconds": v[1], "work": v[2]} for k, v in agg.items()}
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def call(name: str, *args, work: float = 0.0):
     """Invoke a status-returning entry point on the current stream; raise on failure."""
-    rc = getattr(load(), name)(stream_ptr(), *args)
+    timer = TIMER
+    if timer is not None and name in timer.names:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(stream_ptr(), *args)
+        e1.record()
+        timer.records.append((name, e0, e1, work))
+    else:
+        rc = getattr(load(), name)(stream_ptr(), *args)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {_ERRORS.get(rc, rc)}")
 

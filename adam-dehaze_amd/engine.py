@@ -217,11 +217,15 @@ class Engine:
             NcP = descs[0][0].NcP
             stats = self._f(total_blocks, 2, NcP)
         row = 0
+        row_i = 0
+        flops_kn = [L.K * L.Nc for L, _ in plans]
         for d, nb, _wp in descs:
             if stats is not None:
                 d.stats = stats.data_ptr() + row * 2 * d.NcP * 4
-            H.call("adh_conv_forward", C.byref(d))
+            # algorithmic FLOPs of this launch: 2 * virtual pixels * taps * real K * real Nc
+            H.call("adh_conv_forward", C.byref(d), work=2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i])
             row += nb
+            row_i += 1
         return stats, total_blocks
 
     def _wgrad(self, plans, x: Act, g_y: torch.Tensor, gC: int, w: torch.Tensor) -> torch.Tensor:
@@ -248,7 +252,8 @@ class Engine:
                 nsplit //= 2
                 slab_elems = nsplit * T * KP * NcP
             slab = self._f(slab_elems)
-            H.call("adh_conv_wgrad", C.byref(d), slab.data_ptr(), nsplit)
+            H.call("adh_conv_wgrad", C.byref(d), slab.data_ptr(), nsplit,
+                   work=2.0 * d.N * d.VH * d.VW * T * L.K * L.Nc)
             H.call("adh_wgrad_reduce", slab.data_ptr(), nsplit, KP, NcP, C.byref(L), dw.data_ptr(), 0)
         return dw
 

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): images/sec, CORUN-Complex fwd+bwd, 512x1024, bs = 8 per GPU (weak scaling),
+plus PSNR of the HIP output against the CPU oracle.  One "step" = train-mode forward of
+HighIntensityDehazeModel(96) on a synthetic foggy batch + L1 loss + backward + Adam update (and, for
+N > 1, the RCCL gradient all-reduce).  fp32 arithmetic (fp32 MFMA) end to end.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant kernel =
+the MFMA gather convolution, timed live with HIP events on the launch stream) and `cpu_baseline`
+(the CPU oracle timed on a bounded sample on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA peak (= vector peak)
+
+
+def synthetic_batch(n, h, w, seed=42):
+    """Synthetic (hazy, clear) frames: low-pass random clear images + the reference's fog model
+    I = J*t + A*(1-t), t = exp(-beta*depth) (/root/reference utils/helpers.py:241-258), level = i % 3."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    clear = torch.rand(n, 3, h, w, generator=g)
+    clear = F.avg_pool2d(F.pad(clear, (2, 2, 2, 2), mode="reflect"), 5, 1)
+    xs = torch.linspace(0, 1, w).view(1, w)
+    ys = torch.linspace(0, 1, h).view(h, 1)
+    depth = 0.3 + 0.7 * torch.sqrt((xs - 0.5) ** 2 + (ys - 0.2) ** 2)
+    u = torch.rand(n, 2, generator=g)
+    ranges = {0: ((0.1, 0.4), (0.5, 0.7)), 1: ((0.4, 0.7), (0.7, 0.9)), 2: ((0.7, 1.0), (0.8, 1.0))}
+    hazy = torch.empty_like(clear)
+    for i in range(n):
+        (b0, b1), (a0, a1) = ranges[i % 3]
+        beta = b0 + (b1 - b0) * float(u[i, 0])
+        A = a0 + (a1 - a0) * float(u[i, 1])
+        t = torch.exp(-beta * depth)
+        hazy[i] = (clear[i] * t + A * (1 - t)).clamp(0, 1)
+    return hazy, clear
+
+
+def cpu_baseline(h, w, threads):
+    """The CPU oracle (oracle/ref_cpu.py, a pinned restatement of the reference) timed on the host:
+    train-mode Complex forward + L1 + backward on ONE 512x1024 image (bounded sample, ~10-30 s)."""
+    import torch.nn.functional as F
+    import adam_dehaze_amd as A
+    from oracle import ref_cpu as R
+    torch.set_num_threads(threads)
+    torch.manual_seed(42)
+    m = A.HighIntensityDehazeModel()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    hazy, clear = synthetic_batch(1, h, w, seed=7)
+    t0 = time.perf_counter()
+    out = R.high_forward(hazy, sd, training=True)
+    loss = F.l1_loss(out, clear)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"1 image {h}x{w}, CORUN-Complex train fwd + L1 + bwd, 1 iteration, {dt:.1f} s, torch CPU oracle"}
+
+
+def psnr_check(model, device):
+    """PSNR / max-abs of the HIP eval output against the CPU oracle on a 1x3x128x256 frame."""
+    from oracle import ref_cpu as R
+    hazy, _ = synthetic_batch(1, 128, 256, seed=11)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        out = model(hazy.to(device)).cpu()
+        ref = R.high_forward(hazy, sd, training=False)
+    model.train(was_training)
+    return R.psnr(out, ref), float((out - ref).abs().max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adam", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import adam_dehaze_amd as A
+    from adam_dehaze_amd import _hip as H
+    from adam_dehaze_amd.loss import l1_loss
+    from adam_dehaze_amd.optim import Adam
+    from adam_dehaze_amd.parallel import GradientSynchronizer
+
+    torch.manual_seed(42)   # identical replicas on every rank
+    model = A.HighIntensityDehazeModel().to(device).train()
+    opt = None if args.no_adam else Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    sync = GradientSynchronizer(list(model.parameters()), world) if world > 1 else None
+
+    hazy, clear = synthetic_batch(args.batch, args.height, args.width, seed=42 + rank)
+    hazy, clear = hazy.to(device), clear.to(device)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        out = model(hazy)
+        loss = l1_loss(out, clear)
+        loss.backward()
+        if sync is not None:
+            sync.all_reduce()
+        if opt is not None:
+            opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    # timed region: exactly K steps between barrier + synchronize on both sides
+    timer = H.KernelTimer({"adh_conv_forward", "adh_conv_wgrad"})
+    H.TIMER = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    H.TIMER = None
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ks = timer.summary()
+        fwd = ks.get("adh_conv_forward", {"launches": 0, "seconds": 0.0, "work": 0.0})
+        wg = ks.get("adh_conv_wgrad", {"launches": 0, "seconds": 0.0, "work": 0.0})
+        # dominant kernel: the MFMA gather convolution (forward + data-gradient launches)
+        ach = fwd["work"] / fwd["seconds"] / 1e12 if fwd["seconds"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (adh_conv_forward: fwd + dgrad launches)",
+                    "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                    "traffic": None, "launches": fwd["launches"],
+                    "avg_launch_ms": 1e3 * fwd["seconds"] / max(1, fwd["launches"]),
+                    "flops_per_launch_avg": fwd["work"] / max(1, fwd["launches"]),
+                    "wgrad": {"achieved": wg["work"] / wg["seconds"] / 1e12 if wg["seconds"] > 0 else 0.0,
+                              "launches": wg["launches"], "seconds": wg["seconds"]},
+                    "conv_seconds_per_step": (fwd["seconds"] + wg["seconds"]) / max(1, args.steps)}
+        psnr_db, max_abs = psnr_check(model, device)
+        result = {
+            "metric": "images/sec CORUN-Complex fwd+bwd 512x1024 bs=8; PSNR vs CPU ref",
+            "value": world * args.batch * args.steps / dt,
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CORUN-Complex (HighIntensityDehazeModel base 96) train-mode fwd + L1 + bwd"
+                                   + ("" if args.no_adam else " + Adam") + (" + RCCL grad all-reduce" if world > 1 else ""),
+                       "per_gpu_batch": args.batch, "global_batch": world * args.batch,
+                       "height": args.height, "width": args.width, "parallelism": f"dp{world}"},
+            "psnr_db_vs_cpu_oracle": psnr_db if psnr_db != float("inf") else 999.0, "max_abs_vs_cpu_oracle": max_abs,
+            "loss": float(loss.detach()),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(args.height, args.width, min(16, os.cpu_count() or 1))
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -219,21 +219,31 @@ def test_conv_transpose_vs_oracle(N, Cin, Cout, Hh, Ww):
 
 def test_complex_fullwidth_vs_oracle_seeded():
     """Full-width CORUN-Complex (base 96) on a 2x3x64x96 synthetic foggy batch vs the CPU oracle:
-    eval output, train output, L1 loss and a sample of parameter gradients."""
+    eval output, train output and L1 loss within 1e-3; parameter gradients of the smooth objective
+    sum(out*g) judged against the oracle run in fp64: this 50-layer random-init train-mode network
+    amplifies fp32 rounding so much that the CPU fp32 oracle itself is several % off the fp64 gradients
+    for some tensors, so the HIP path must be as close to fp64 as the fp32 CPU path is (3x + 2e-3)."""
     from adam_dehaze_amd.loss import l1_loss
     torch.manual_seed(42)
     m = A.HighIntensityDehazeModel()
     sd_cpu = {k: v.clone() for k, v in m.state_dict().items()}
     hazy, clear, _ = R.synthetic_batch(2, 64, 96, seed=42)
+    gout = torch.randn(hazy.shape, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
         ref_eval = R.high_forward(hazy, {k: v.clone() for k, v in sd_cpu.items()}, training=False)
-    sd_tr = {k: v.clone() for k, v in sd_cpu.items()}
-    for k, v in sd_tr.items():
-        if v.is_floating_point() and "running" not in k:
-            v.requires_grad_(True)
-    ref_train = R.high_forward(hazy, sd_tr, training=True)
+
+    def oracle(dtype):
+        sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd_cpu.items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+        out = R.high_forward(hazy.to(dtype), sd, training=True)
+        (out * gout.to(dtype)).sum().backward()
+        return out.detach(), sd
+
+    ref_train, sd32 = oracle(torch.float32)
+    _, sd64 = oracle(torch.float64)
     ref_loss = F.l1_loss(ref_train, clear)
-    ref_loss.backward()
 
     m = m.to(DEV)
     m.eval()
@@ -243,20 +253,23 @@ def test_complex_fullwidth_vs_oracle_seeded():
     assert R.psnr(out.cpu(), ref_eval) > 60.0
     m.train()
     out = m(hazy.to(DEV))
-    assert max_abs(out, ref_train.detach()) < 1e-3
+    assert max_abs(out, ref_train) < 1e-3
     loss = l1_loss(out, clear.to(DEV))
     assert abs(float(loss) - float(ref_loss)) < 1e-4
-    loss.backward()
+    out.backward(gout.to(DEV))
     bad = []
     for name, p in m.named_parameters():
-        ref = sd_tr[name].grad
-        if ref is None:
+        g64 = sd64[name].grad
+        if g64 is None:
             continue
-        scale = max(float(ref.abs().max()), 1e-8)
-        err = float((p.grad.cpu() - ref).abs().max())
-        if not err < 2e-2 * scale + 1e-7:
-            bad.append((name, err, scale))
+        scale = max(float(g64.abs().max()), 1e-6)
+        if name.endswith(".bias") and name.split(".")[-2] == "0" and "decoder" in name:
+            continue   # ConvTranspose bias feeding train-mode BN: true gradient is exactly 0 (pure noise)
+        err_cpu = float((sd32[name].grad.double() - g64).abs().max()) / scale
+        err_gpu = float((p.grad.cpu().double() - g64).abs().max()) / scale
+        if not err_gpu <= 3.0 * err_cpu + 2e-3:
+            bad.append((name, err_gpu, err_cpu))
     assert not bad, bad[:8]
     for k, v in m.state_dict().items():
         if "running" in k:
-            assert max_abs(v, sd_tr[k]) < 1e-4, k
+            assert max_abs(v, sd32[k]) < 1e-4, k
