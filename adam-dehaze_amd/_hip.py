@@ -74,12 +74,15 @@ _SIGNATURES = {
     "adh_cbam_bwd_d": [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32],
     "adh_cbam_bwd_e": [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32],
     "adh_image_to_nhwc8": [vp, vp, i32, i32, i32, vp],
+    "adh_image_normalize_to_nhwc8": [vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, f32, vp],
+    "adh_image_normalize_bwd": [vp, vp, i32, i32, i32, i32, f32, f32, f32, vp],
     "adh_nchw_to_nhwc": [vp, vp, i32, i32, i32, i32, vp, i32],
     "adh_nhwc_to_nchw": [vp, vp, i32, i32, i32, i32, i32, vp],
     "adh_head_blend": [vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     "adh_head_blend_bwd": [vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, i32],
     "adh_head_blend_bwd_num_blocks": [i32, i32, i32],
     "adh_softmax3": [vp, vp, f32, i32, vp],
+    "adh_softmax3_bwd": [vp, vp, vp, i32, f32, i32, vp],
     "adh_soft_blend": [vp, vp, vp, vp, vp, i32, i64, vp],
     "adh_soft_blend_bwd": [vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, i32],
     "adh_argmax3": [vp, vp, i32, vp],
@@ -96,8 +99,11 @@ _SIGNATURES = {
     "adh_adam_step": [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32],
     "adh_add_inplace": [vp, vp, vp, i64],
     "adh_axpby_strided": [vp, vp, i32, vp, i32, i64, i32, f32, f32],
-    "adh_maxpool": [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp],
-    "adh_maxpool_bwd": [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32],
+    "adh_maxpool": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
+    "adh_maxpool_bwd": [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32],
+    "adh_mul": [vp, vp, vp, vp, i64],
+    "adh_avgpool": [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32],
+    "adh_global_avgpool_bwd": [vp, vp, i32, i32, i32, vp, i32],
     "adh_bilinear": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32],
     "adh_bilinear_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32],
 }

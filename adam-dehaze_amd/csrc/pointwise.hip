@@ -31,6 +31,51 @@ extern "C" int adh_image_to_nhwc8(void* stream, const float* img, int N, int H, 
     return adh_check_launch();
 }
 
+__global__ void image_normalize_kernel(const float* __restrict__ img, int64_t HW, int64_t total, float m0, float m1, float m2,
+                                       float is0, float is1, float is2, float* __restrict__ out) {
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = idx / HW, p = idx - n * HW;
+        const float* b = img + n * 3 * HW + p;
+        f32x4 lo = {(b[0] - m0) * is0, (b[HW] - m1) * is1, (b[2 * HW] - m2) * is2, 0.f};
+        f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+        f32x4* o = reinterpret_cast<f32x4*>(out + idx * 8);
+        o[0] = lo;
+        o[1] = hi;
+    }
+}
+
+extern "C" int adh_image_normalize_to_nhwc8(void* stream, const float* img, int N, int H, int W, float m0, float m1, float m2,
+                                            float is0, float is1, float is2, float* out) {
+    if (!img || !out || N < 1 || H < 1 || W < 1) return ADH_E_ARG;
+    const int64_t HW = (int64_t)H * W, total = HW * N;
+    hipLaunchKernelGGL(image_normalize_kernel, dim3(adh_min_i(adh_ceil_div(total, 256), 8192)), dim3(256), 0,
+                       (hipStream_t)stream, img, HW, total, m0, m1, m2, is0, is1, is2, out);
+    return adh_check_launch();
+}
+
+__global__ void image_normalize_bwd_kernel(const float* __restrict__ g, int g_cs, int64_t HW, int64_t total, float is0,
+                                           float is1, float is2, float* __restrict__ gimg) {
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = idx / HW, p = idx - n * HW;
+        const float* gp = g + idx * g_cs;
+        float* b = gimg + n * 3 * HW + p;
+        b[0] = gp[0] * is0;
+        b[HW] = gp[1] * is1;
+        b[2 * HW] = gp[2] * is2;
+    }
+}
+
+extern "C" int adh_image_normalize_bwd(void* stream, const float* g, int g_cs, int N, int H, int W, float is0, float is1,
+                                       float is2, float* g_img) {
+    if (!g || !g_img || N < 1 || g_cs < 3) return ADH_E_ARG;
+    const int64_t HW = (int64_t)H * W, total = HW * N;
+    hipLaunchKernelGGL(image_normalize_bwd_kernel, dim3(adh_min_i(adh_ceil_div(total, 256), 8192)), dim3(256), 0,
+                       (hipStream_t)stream, g, g_cs, HW, total, is0, is1, is2, g_img);
+    return adh_check_launch();
+}
+
 // generic transposes through a 32x33 LDS tile: src [n][C][HW] <-> dst [n][HW][cs]
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, int C, int64_t HW, float* __restrict__ dst, int dst_cs) {
     __shared__ float tile[32][33];
@@ -225,6 +270,28 @@ extern "C" int adh_softmax3(void* stream, const float* logits, float temperature
     if (!logits || !weights || N < 1 || temperature == 0.f) return ADH_E_ARG;
     hipLaunchKernelGGL(softmax3_kernel, dim3(adh_ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, logits,
                        1.0f / temperature, N, weights);
+    return adh_check_launch();
+}
+
+__global__ void softmax3_bwd_kernel(const float* __restrict__ w, const float* __restrict__ gw_partial, int nblk, float invT,
+                                    int N, float* __restrict__ gl) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double g[3] = {0.0, 0.0, 0.0};
+    for (int b = 0; b < nblk; ++b)
+        for (int i = 0; i < 3; ++i) g[i] += (double)gw_partial[((size_t)n * nblk + b) * 3 + i];
+    const float w0 = w[n * 3], w1 = w[n * 3 + 1], w2 = w[n * 3 + 2];
+    const float dot = (float)g[0] * w0 + (float)g[1] * w1 + (float)g[2] * w2;
+    gl[n * 3] = w0 * ((float)g[0] - dot) * invT;
+    gl[n * 3 + 1] = w1 * ((float)g[1] - dot) * invT;
+    gl[n * 3 + 2] = w2 * ((float)g[2] - dot) * invT;
+}
+
+extern "C" int adh_softmax3_bwd(void* stream, const float* weights, const float* gw_partial, int nblk, float temperature,
+                                int N, float* g_logits) {
+    if (!weights || !gw_partial || !g_logits || N < 1 || nblk < 1 || temperature == 0.f) return ADH_E_ARG;
+    hipLaunchKernelGGL(softmax3_bwd_kernel, dim3(adh_ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, weights,
+                       gw_partial, nblk, 1.0f / temperature, N, g_logits);
     return adh_check_launch();
 }
 
@@ -555,10 +622,11 @@ extern "C" int adh_axpby_strided(void* stream, float* dst, int dst_cs, const flo
     return adh_check_launch();
 }
 
-// MaxPool2d(k, stride k) (medium_intensity.py:145,150; high_intensity.py:162,165); idx = winning input pixel
+// MaxPool2d(k, stride, pad) (medium_intensity.py:145,150; high_intensity.py:162,165; torchvision resnet/densenet
+// stem pool k3 s2 p1); idx = winning input pixel, first on ties (scan order = ATen's)
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, int x_cs, int H, int W, int CQ, int k,
-                                                      int OH, int OW, float* __restrict__ out, int out_cs,
-                                                      int32_t* __restrict__ idx) {
+                                                      int stride, int pad, int OH, int OW, float* __restrict__ out,
+                                                      int out_cs, int32_t* __restrict__ idx) {
     const int n = blockIdx.y;
     const int64_t total = (int64_t)OH * OW * CQ;
     const float* xn = x + (size_t)n * H * W * x_cs;
@@ -567,18 +635,23 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
         const int c = (int)(t - op * CQ) * 4;
         const int oy = (int)(op / OW), ox = (int)(op - (int64_t)oy * OW);
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int mi[4] = {0, 0, 0, 0};
-        for (int dy = 0; dy < k; ++dy)
+        int mi[4] = {-1, -1, -1, -1};
+        for (int dy = 0; dy < k; ++dy) {
+            const int iy = oy * stride - pad + dy;
+            if (iy < 0 || iy >= H) continue;
             for (int dx = 0; dx < k; ++dx) {
-                const int ip = (oy * k + dy) * W + ox * k + dx;
+                const int ix = ox * stride - pad + dx;
+                if (ix < 0 || ix >= W) continue;
+                const int ip = iy * W + ix;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (size_t)ip * x_cs + c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (v[j] > m[j]) {
+                    if (v[j] > m[j] || mi[j] < 0) {
                         m[j] = v[j];
                         mi[j] = ip;
                     }
             }
+        }
         const size_t o = (size_t)n * OH * OW + op;
         *reinterpret_cast<f32x4*>(out + o * out_cs + c) = m;
         if (idx) {
@@ -588,40 +661,105 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
     }
 }
 
-extern "C" int adh_maxpool(void* stream, const float* x, int x_cs, int N, int H, int W, int C, int k, float* out, int out_cs,
-                           int32_t* idx) {
-    if (!x || !out || k < 1 || C < 4 || (C & 3) || H < k || W < k) return ADH_E_ARG;
-    const int OH = H / k, OW = W / k;
+extern "C" int adh_maxpool(void* stream, const float* x, int x_cs, int N, int H, int W, int C, int k, int stride, int pad,
+                           float* out, int out_cs, int32_t* idx) {
+    if (!x || !out || k < 1 || stride < 1 || pad < 0 || pad > k / 2 || C < 4 || (C & 3)) return ADH_E_ARG;
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    if (OH < 1 || OW < 1) return ADH_E_ARG;
     hipLaunchKernelGGL(maxpool_kernel, dim3(adh_min_i(adh_ceil_div((int64_t)OH * OW * (C / 4), 256), 4096), N), dim3(256), 0,
-                       (hipStream_t)stream, x, x_cs, H, W, C / 4, k, OH, OW, out, out_cs, idx);
+                       (hipStream_t)stream, x, x_cs, H, W, C / 4, k, stride, pad, OH, OW, out, out_cs, idx);
     return adh_check_launch();
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ g, int g_cs,
                                                           const int32_t* __restrict__ idx, int OH, int OW, int C, int k,
-                                                          int H, int W, float* __restrict__ gx, int gx_cs) {
-    // gather form: every input pixel looks at the one window that covers it (stride == kernel)
+                                                          int stride, int pad, int H, int W, float* __restrict__ gx,
+                                                          int gx_cs) {
+    // gather form: every input pixel sums the windows that cover it and elected it (deterministic)
     const int n = blockIdx.y;
     const int64_t total = (int64_t)H * W * C;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ip = t / C;
         const int c = (int)(t - ip * C);
         const int iy = (int)(ip / W), ix = (int)(ip - (int64_t)iy * W);
-        const int oy = iy / k, ox = ix / k;
         float v = 0.f;
-        if (oy < OH && ox < OW) {
-            const size_t o = (size_t)n * OH * OW + (size_t)oy * OW + ox;
-            if (idx[o * C + c] == (int)ip) v = g[o * g_cs + c];
-        }
+        // windows oy with oy*stride - pad <= iy <= oy*stride - pad + k - 1
+        int oy_lo = (iy + pad - k + 1 + stride - 1) / stride;
+        if (iy + pad - k + 1 < 0) oy_lo = 0;
+        const int oy_hi = adh_min_i((iy + pad) / stride, OH - 1);
+        int ox_lo = (ix + pad - k + 1 + stride - 1) / stride;
+        if (ix + pad - k + 1 < 0) ox_lo = 0;
+        const int ox_hi = adh_min_i((ix + pad) / stride, OW - 1);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const size_t o = (size_t)n * OH * OW + (size_t)oy * OW + ox;
+                if (idx[o * C + c] == (int)ip) v += g[o * g_cs + c];
+            }
         gx[((size_t)n * H * W + ip) * gx_cs + c] = v;
     }
 }
 
 extern "C" int adh_maxpool_bwd(void* stream, const float* g, int g_cs, const int32_t* idx, int N, int OH, int OW, int C,
-                               int k, int H, int W, float* gx, int gx_cs) {
-    if (!g || !idx || !gx) return ADH_E_ARG;
+                               int k, int stride, int pad, int H, int W, float* gx, int gx_cs) {
+    if (!g || !idx || !gx || k < 1 || stride < 1) return ADH_E_ARG;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(adh_min_i(adh_ceil_div((int64_t)H * W * C, 256), 4096), N), dim3(256), 0,
-                       (hipStream_t)stream, g, g_cs, idx, OH, OW, C, k, H, W, gx, gx_cs);
+                       (hipStream_t)stream, g, g_cs, idx, OH, OW, C, k, stride, pad, H, W, gx, gx_cs);
+    return adh_check_launch();
+}
+
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, int x_cs, int H, int W, int CQ, int k,
+                                                      int OH, int OW, float* __restrict__ out, int out_cs) {
+    const int n = blockIdx.y;
+    const int64_t total = (int64_t)OH * OW * CQ;
+    const float* xn = x + (size_t)n * H * W * x_cs;
+    const float inv = 1.0f / (float)(k * k);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t op = t / CQ;
+        const int c = (int)(t - op * CQ) * 4;
+        const int oy = (int)(op / OW), ox = (int)(op - (int64_t)oy * OW);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx)
+                s += *reinterpret_cast<const f32x4*>(xn + ((size_t)(oy * k + dy) * W + ox * k + dx) * x_cs + c);
+        *reinterpret_cast<f32x4*>(out + ((size_t)n * OH * OW + op) * out_cs + c) = s * inv;
+    }
+}
+
+extern "C" int adh_avgpool(void* stream, const float* x, int x_cs, int N, int H, int W, int C, int k, float* out, int out_cs) {
+    if (!x || !out || k < 1 || C < 4 || (C & 3) || H < k || W < k) return ADH_E_ARG;
+    const int OH = H / k, OW = W / k;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(adh_min_i(adh_ceil_div((int64_t)OH * OW * (C / 4), 256), 4096), N), dim3(256), 0,
+                       (hipStream_t)stream, x, x_cs, H, W, C / 4, k, OH, OW, out, out_cs);
+    return adh_check_launch();
+}
+
+__global__ __launch_bounds__(256) void global_avgpool_bwd_kernel(const float* __restrict__ g, int HW, int C,
+                                                                 float* __restrict__ gx, int gx_cs) {
+    const int n = blockIdx.y;
+    const int64_t total = (int64_t)HW * C;
+    const float inv = 1.0f / (float)HW;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = t / C;
+        const int c = (int)(t - p * C);
+        gx[((size_t)n * HW + p) * gx_cs + c] = g[(size_t)n * C + c] * inv;
+    }
+}
+
+extern "C" int adh_global_avgpool_bwd(void* stream, const float* g, int N, int HW, int C, float* gx, int gx_cs) {
+    if (!g || !gx || N < 1 || HW < 1 || C < 1) return ADH_E_ARG;
+    hipLaunchKernelGGL(global_avgpool_bwd_kernel, dim3(adh_min_i(adh_ceil_div((int64_t)HW * C, 256), 2048), N), dim3(256), 0,
+                       (hipStream_t)stream, g, HW, C, gx, gx_cs);
+    return adh_check_launch();
+}
+
+__global__ void mul_kernel(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = a[i] * b[i];
+}
+
+extern "C" int adh_mul(void* stream, float* dst, const float* a, const float* b, int64_t n) {
+    if (!dst || !a || !b || n < 1) return ADH_E_ARG;
+    hipLaunchKernelGGL(mul_kernel, dim3(adh_min_i(adh_ceil_div(n, 256), 8192)), dim3(256), 0, (hipStream_t)stream, dst, a, b, n);
     return adh_check_launch();
 }
 

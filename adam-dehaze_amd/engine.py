@@ -80,13 +80,15 @@ class Engine:
         self.tape: List[Callable[[], None]] = []
         self.param_grads: Dict[int, torch.Tensor] = {}   # id(param) -> grad
         self.params: Dict[int, torch.Tensor] = {}
+        self.alias: Dict[int, int] = {}                  # id(reshaped view of a param) -> id(param)
+        self.upstream: Dict[str, torch.Tensor] = {}      # 'g': device scalar cotangent of a scalar loss
 
     # ------------------------------------------------------------------ helpers
     def _f(self, *shape, zero=False):
         return (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=torch.float32)
 
     def add_param_grad(self, p: torch.Tensor, g: torch.Tensor):
-        k = id(p)
+        k = self.alias.get(id(p), id(p))
         if k in self.param_grads:
             H.call("adh_add_inplace", self.param_grads[k].data_ptr(), g.data_ptr(), g.numel())
         else:
@@ -114,6 +116,48 @@ class Engine:
         out = self._f(N, Hh, Ww, 8)
         H.call("adh_image_to_nhwc8", x.data_ptr(), N, Hh, Ww, out.data_ptr())
         return Act(out, 8, needs_grad=False)
+
+    def image_normalize_to_nhwc8(self, x: torch.Tensor, mean, std, holder: dict) -> Act:
+        """(x - mean[c]) / std[c] -> NHWC8 (loss.py:60-66); the gradient wrt the NCHW image is left in
+        holder['gx'] by the backward closure."""
+        N, Cc, Hh, Ww = x.shape
+        out = self._f(N, Hh, Ww, 8)
+        inv = [1.0 / s_ for s_ in std]
+        H.call("adh_image_normalize_to_nhwc8", x.data_ptr(), N, Hh, Ww, mean[0], mean[1], mean[2], inv[0], inv[1], inv[2],
+               out.data_ptr())
+        a = Act(out, 8, needs_grad=self.record)
+        if self.record:
+            def bwd():
+                g = a.grad
+                a.grad = None
+                if g is None:
+                    return
+                gx = torch.empty_like(x)
+                H.call("adh_image_normalize_bwd", g.data_ptr(), g.stride(2), N, Hh, Ww, inv[0], inv[1], inv[2], gx.data_ptr())
+                holder["gx"] = gx
+            self.tape.append(bwd)
+        return a
+
+    def mse(self, a: Act, b: Act, scale: float, sink: list):
+        """sink.append(device scalar mean((a-b)^2) * scale) (F.mse_loss, loss.py:81); gradient flows to `a` only."""
+        assert a.t.is_contiguous() and b.t.is_contiguous() and a.t.shape == b.t.shape
+        n = a.t.numel()
+        nblk = H.value("adh_reduce_num_blocks", n)
+        partial = self._f(nblk)
+        val = self._f(1)
+        H.call("adh_mse_partial", a.t.data_ptr(), b.t.data_ptr(), n, partial.data_ptr())
+        H.call("adh_sum_partials", partial.data_ptr(), nblk, scale / n, val.data_ptr())
+        sink.append(val)
+        if self.record:
+            def bwd():
+                up = sink_grad.get("g")
+                if up is None or not a.needs_grad:
+                    return
+                ga = self._f(*a.t.shape)
+                H.call("adh_mse_bwd", a.t.data_ptr(), b.t.data_ptr(), n, scale / n, up.data_ptr(), ga.data_ptr())
+                self.accum(a, ga)
+            sink_grad = self.upstream
+            self.tape.append(bwd)
 
     # ------------------------------------------------------------------ convolution family
     @staticmethod
@@ -375,8 +419,9 @@ class Engine:
                 self.add_param_grad(b, self._channel_sum(g_y, Cout))
         if g_res is not None:
             self.accum(residual, g_res)
-        # weight gradient
-        self.add_param_grad(w, self._wgrad(self._launch_plan(kind, k, stride, pad, w, "fwd"), x, g_y, Cout, w))
+        # weight gradient (skipped for frozen weights, e.g. the VGG16 feature extractor of the content loss)
+        if w.requires_grad or self.alias.get(id(w)) is not None:
+            self.add_param_grad(w, self._wgrad(self._launch_plan(kind, k, stride, pad, w, "fwd"), x, g_y, Cout, w))
         # data gradient
         if x.needs_grad:
             plans = self._launch_plan(kind, k, stride, pad, w, "dgrad")
@@ -482,12 +527,13 @@ class Engine:
         return o
 
     # ------------------------------------------------------------------ pooling / resize (alt models, odd sizes)
-    def maxpool(self, x: Act, k: int) -> Act:
+    def maxpool(self, x: Act, k: int, stride: Optional[int] = None, pad: int = 0) -> Act:
+        stride = k if stride is None else stride
         N, Hh, Ww, Cc = x.N, x.Hh, x.Ww, x.C
-        OH, OW = Hh // k, Ww // k
+        OH, OW = (Hh + 2 * pad - k) // stride + 1, (Ww + 2 * pad - k) // stride + 1
         out = self._f(N, OH, OW, Cc)
         idx = torch.empty((N, OH, OW, Cc), device=self.device, dtype=torch.int32) if self.record else None
-        H.call("adh_maxpool", x.t.data_ptr(), x.cs, N, Hh, Ww, Cc, k, out.data_ptr(), Cc, H.ptr(idx))
+        H.call("adh_maxpool", x.t.data_ptr(), x.cs, N, Hh, Ww, Cc, k, stride, pad, out.data_ptr(), Cc, H.ptr(idx))
         o = Act(out, Cc)
         if self.record:
             def bwd():
@@ -496,7 +542,7 @@ class Engine:
                 if g is None or not x.needs_grad:
                     return
                 gx = self._f(N, Hh, Ww, Cc)
-                H.call("adh_maxpool_bwd", g.data_ptr(), g.stride(2), idx.data_ptr(), N, OH, OW, Cc, k, Hh, Ww,
+                H.call("adh_maxpool_bwd", g.data_ptr(), g.stride(2), idx.data_ptr(), N, OH, OW, Cc, k, stride, pad, Hh, Ww,
                        gx.data_ptr(), Cc)
                 self.accum(x, gx)
             self.tape.append(bwd)
@@ -518,6 +564,70 @@ class Engine:
                 gx = self._f(N, Hh, Ww, Cc, zero=True)
                 H.call("adh_bilinear_bwd", g.data_ptr(), g.stride(2), N, Hh, Ww, Cc, OH, OW, int(align_corners),
                        gx.data_ptr(), Cc)
+                self.accum(x, gx)
+            self.tape.append(bwd)
+        return o
+
+    # ------------------------------------------------------------------ classifier helpers
+    def global_avgpool(self, x: Act) -> Act:
+        """AdaptiveAvgPool2d(1) -> [N,1,1,C] (torchvision resnet/densenet); reuses the CBAM pooling kernels."""
+        N, Hh, Ww, Cc = x.N, x.Hh, x.Ww, x.C
+        HW = Hh * Ww
+        nblk = H.value("adh_cbam_pool_num_blocks", HW)
+        partial = self._f(N, nblk, 2, Cc)
+        partial_idx = torch.empty((N, nblk, Cc), device=self.device, dtype=torch.int32)
+        pooled = self._f(N, 2, Cc)
+        amax_idx = torch.empty((N, Cc), device=self.device, dtype=torch.int32)
+        H.call("adh_cbam_pool", x.t.data_ptr(), x.cs, N, HW, Cc, partial.data_ptr(), partial_idx.data_ptr(), nblk,
+               pooled.data_ptr(), amax_idx.data_ptr())
+        o = Act(pooled[:, 0, :].contiguous().view(N, 1, 1, Cc), Cc)   # [N,1,1,C] means
+        if self.record:
+            def bwd():
+                g = o.grad
+                o.grad = None
+                if g is None or not x.needs_grad:
+                    return
+                gc = g.reshape(N, -1)[:, :Cc].contiguous()
+                gx = self._f(N, Hh, Ww, Cc)
+                H.call("adh_global_avgpool_bwd", gc.data_ptr(), N, HW, Cc, gx.data_ptr(), Cc)
+                self.accum(x, gx)
+            self.tape.append(bwd)
+        return o
+
+    def avgpool(self, x: Act, k: int) -> Act:
+        assert not self.record, "avgpool backward is not implemented (DenseNet121 runs forward-only)"
+        N, Hh, Ww, Cc = x.N, x.Hh, x.Ww, x.C
+        out = self._f(N, Hh // k, Ww // k, Cc)
+        H.call("adh_avgpool", x.t.data_ptr(), x.cs, N, Hh, Ww, Cc, k, out.data_ptr(), Cc)
+        return Act(out, Cc)
+
+    def bn_relu_eval(self, x: Act, bn: BNState, out: Optional[torch.Tensor] = None) -> Act:
+        """Stand-alone eval-mode BatchNorm + ReLU (DenseNet's pre-activation norm layers)."""
+        assert not self.record, "pre-activation BN backward is not implemented (DenseNet121 runs forward-only)"
+        N, Hh, Ww, Cc = x.N, x.Hh, x.Ww, x.C
+        scale, shift = self._f(Cc), self._f(Cc)
+        H.call("adh_bn_fold_eval", Cc, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+               bn.running_var.data_ptr(), BN_EPS, None, scale.data_ptr(), shift.data_ptr())
+        if out is None:
+            out = self._f(N, Hh, Ww, Cc)
+        H.call("adh_bn_apply", x.t.data_ptr(), x.cs, scale.data_ptr(), shift.data_ptr(), None, 0, H.ACT_RELU,
+               out.data_ptr(), out.stride(2), x.pixels, Cc)
+        return Act(out, Cc)
+
+    def mul_mask(self, x: Act, mask: torch.Tensor) -> Act:
+        """x * mask (dropout with a pre-drawn, pre-scaled mask of x's shape and strides)."""
+        assert x.t.is_contiguous() and mask.shape == x.t.shape
+        out = self._f(*x.t.shape)
+        H.call("adh_mul", out.data_ptr(), x.t.data_ptr(), mask.data_ptr(), out.numel())
+        o = Act(out, x.C)
+        if self.record:
+            def bwd():
+                g = o.grad
+                o.grad = None
+                if g is None or not x.needs_grad:
+                    return
+                gx = self._f(*x.t.shape)
+                H.call("adh_mul", gx.data_ptr(), g.contiguous().data_ptr(), mask.data_ptr(), gx.numel())
                 self.accum(x, gx)
             self.tape.append(bwd)
         return o

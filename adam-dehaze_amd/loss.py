@@ -112,6 +112,119 @@ def cross_entropy3(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return _CE3Fn.apply(logits, labels)
 
 
+VGG16_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class _ContentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, pred, target, *params):
+        from .engine import Engine
+        rec = ctx.needs_input_grad[1]
+        taps = module.tap_indices
+        scale = 1.0 / len(taps)
+        # target features: no gradient
+        eng_t = Engine(pred.device, False)
+        feats_t = module._features(eng_t, target.contiguous(), taps, {})
+        eng = Engine(pred.device, rec)
+        holder = {}
+        feats_p = module._features(eng, pred.contiguous(), taps, holder)
+        vals = []
+        for fp, ft in zip(feats_p, feats_t):
+            eng.mse(fp, ft, scale, vals)
+        total = vals[0].clone()
+        for v in vals[1:]:
+            H.call("adh_add_inplace", total.data_ptr(), v.data_ptr(), 1)
+        ctx.eng, ctx.holder = eng, holder
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        eng = ctx.eng
+        eng.upstream["g"] = g.contiguous().reshape(1)
+        eng.backward()
+        gx = ctx.holder.get("gx")
+        ctx.eng = None
+        return (None, gx, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 3))
+
+
+class ContentLoss(nn.Module):
+    """Content loss on VGG features (loss.py:7-84): ImageNet-normalise, then mean over the taps
+    ['relu2_2','relu3_3','relu4_3'] of mse(features[:idx+1](x), features[:idx+1](target)) with the reference's
+    layer_mapping (idx 9/16/23 = the MaxPool layers after those relus in torchvision's vgg16.features).
+    One pass per image with three taps replaces the reference's six prefix passes (identical values).
+    Weights: `model.{idx}.weight/bias` (torchvision naming); pretrained weights cannot be downloaded here,
+    load them with load_state_dict.  The extractor is frozen (loss.py:27-28)."""
+
+    LAYER_MAPPING = {"relu1_1": 2, "relu1_2": 4, "relu2_1": 7, "relu2_2": 9, "relu3_1": 12, "relu3_2": 14, "relu3_3": 16,
+                     "relu4_1": 19, "relu4_2": 21, "relu4_3": 23, "relu5_1": 26, "relu5_2": 28, "relu5_3": 30}
+
+    def __init__(self, pretrained_model="vgg16", content_layers=None):
+        super().__init__()
+        from .layers import ConvParams, Seq
+        if content_layers is None:
+            content_layers = ["relu2_2", "relu3_3", "relu4_3"]
+        self.content_layers = content_layers
+        if pretrained_model == "vgg16":
+            cfg = VGG16_CFG
+        elif pretrained_model == "vgg19":
+            cfg = VGG19_CFG
+        else:
+            raise ValueError(f"Unsupported model: {pretrained_model}")
+        items, idx, cin = [], 0, 3
+        self.plan = []   # ('conv', idx) | ('relu', idx) | ('pool', idx)
+        for v in cfg:
+            if v == "M":
+                self.plan.append(("pool", idx))
+                idx += 1
+            else:
+                items.append((idx, ConvParams(cin, v, 3, bias=True)))
+                self.plan.append(("conv", idx))
+                self.plan.append(("relu", idx + 1))
+                cin = v
+                idx += 2
+        self.model = Seq(items)
+        for p in self.model.parameters():
+            p.requires_grad = False
+        self.tap_indices = [self.LAYER_MAPPING[n] for n in content_layers]
+
+    def _features(self, eng, img, taps, holder):
+        h = eng.image_normalize_to_nhwc8(img, IMAGENET_MEAN, IMAGENET_STD, holder)
+        feats, last = [], max(taps)
+        i = 0
+        plan = self.plan
+        while i < len(plan):
+            kind, idx = plan[i]
+            if idx > last:
+                break
+            if kind == "conv":
+                p = self.model.at(idx)
+                # features[:idx+1] ending ON a conv index (never the case for the reference's mapping) would
+                # exclude the relu; the mapping's indices are relu / pool outputs, so conv+relu fuse safely
+                fuse_relu = (idx + 1) <= last and idx not in taps
+                h = eng.conv(h, p.weight, p.bias, None, k=3, stride=1, pad=1, relu=fuse_relu)
+                if idx in taps:
+                    feats.append(h)
+                i += 2 if fuse_relu else 1
+                if fuse_relu and (idx + 1) in taps:
+                    feats.append(h)
+                continue
+            if kind == "pool":
+                h = eng.maxpool(h, 2)
+                if idx in taps:
+                    feats.append(h)
+            i += 1
+        return feats
+
+    def forward(self, x, target):
+        H.require_cuda(x, "prediction")
+        H.require_cuda(target, "target")
+        params = list(self.model.parameters())
+        return _ContentFn.apply(self, x, target, *params)
+
+
 class DehazingLoss(nn.Module):
     """Combined loss for image dehazing (loss.py:110-162)."""
 

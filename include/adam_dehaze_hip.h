@@ -170,6 +170,12 @@ int adh_cbam_bwd_e(void* stream, const float* g, int g_cs, const float* x, int x
 /* ---- boundary layout + branch heads ------------------------------------------------------------ */
 /* NCHW [N,3,H,W] image -> NHWC with cstride 8 (channels 3..7 zero) */
 int adh_image_to_nhwc8(void* stream, const float* img, int N, int H, int W, float* out);
+/* ImageNet-style normalisation fused with the layout change: out[..., c] = (img[c] - mean_c) * inv_std_c
+ * (training/loss.py:60-66), and its adjoint g_img[c] = g[..., c] * inv_std_c */
+int adh_image_normalize_to_nhwc8(void* stream, const float* img, int N, int H, int W, float m0, float m1, float m2,
+                                 float is0, float is1, float is2, float* out);
+int adh_image_normalize_bwd(void* stream, const float* g, int g_cs, int N, int H, int W, float is0, float is1, float is2,
+                            float* g_img);
 /* generic NCHW <-> NHWC (classifier features / tests) */
 int adh_nchw_to_nhwc(void* stream, const float* src, int N, int C, int H, int W, float* dst, int dst_cs);
 int adh_nhwc_to_nchw(void* stream, const float* src, int src_cs, int N, int C, int H, int W, float* dst);
@@ -192,6 +198,10 @@ int adh_head_blend_bwd_num_blocks(int N, int H, int W);
 /* ---- routing (models/routing.py:41-61,110-127) ----------------------------------------------------- */
 /* weights[n][3] = softmax(logits[n]/T); out = sum_i weights[n][i]*branch_i  (NCHW images, per = 3*H*W) */
 int adh_softmax3(void* stream, const float* logits, float temperature, int N, float* weights);
+/* g_logits[n][3] from the blend's weight gradients: gw[n][i] = sum_blk gw_partial[n][blk][i];
+ * g_logits = w * (gw - sum_j gw_j w_j) / T  (softmax backward, routing.py:111) */
+int adh_softmax3_bwd(void* stream, const float* weights, const float* gw_partial, int nblk, float temperature, int N,
+                     float* g_logits);
 int adh_soft_blend(void* stream, const float* weights, const float* o0, const float* o1, const float* o2,
                    int N, int64_t per, float* out);
 /* backward: g_oi = w[n][i]*g; gw_partial[n][nblk][3] = sum g*o_i */
@@ -228,10 +238,16 @@ int adh_adam_step(void* stream, float* p, const float* g, float* m, float* v, in
 int adh_add_inplace(void* stream, float* dst, const float* src, int64_t n);            /* dst += src */
 int adh_axpby_strided(void* stream, float* dst, int dst_cs, const float* src, int src_cs,
                       int64_t P, int C, float a, float b);                           /* dst = a*dst + b*src */
-int adh_maxpool(void* stream, const float* x, int x_cs, int N, int H, int W, int C, int k, float* out, int out_cs,
-                int32_t* idx);
+/* MaxPool2d(k, stride, pad) with -inf padding; idx[n][oy][ox][c] = winning input pixel (first on ties) */
+int adh_maxpool(void* stream, const float* x, int x_cs, int N, int H, int W, int C, int k, int stride, int pad,
+                float* out, int out_cs, int32_t* idx);
 int adh_maxpool_bwd(void* stream, const float* g, int g_cs, const int32_t* idx, int N, int OH, int OW, int C, int k,
-                    int H, int W, float* gx, int gx_cs);
+                    int stride, int pad, int H, int W, float* gx, int gx_cs);
+int adh_mul(void* stream, float* dst, const float* a, const float* b, int64_t n);       /* dst = a*b */
+/* AvgPool2d(k, stride k) forward (torchvision densenet transition) */
+int adh_avgpool(void* stream, const float* x, int x_cs, int N, int H, int W, int C, int k, float* out, int out_cs);
+/* adjoint of the global average pool: gx[n][p][c] = g[n][c] / HW (torchvision resnet avgpool) */
+int adh_global_avgpool_bwd(void* stream, const float* g, int N, int HW, int C, float* gx, int gx_cs);
 /* bilinear resize, align_corners 0/1 (medium_intensity.py:93-99,147,152) and its adjoint */
 int adh_bilinear(void* stream, const float* x, int x_cs, int N, int H, int W, int C, int OH, int OW,
                  int align_corners, float* out, int out_cs);
