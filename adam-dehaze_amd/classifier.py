@@ -171,8 +171,7 @@ class _DenseNet121(nn.Module):
 
 class _ClassifierFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, x, masks, *params):
-        record = any(ctx.needs_input_grad[3:])
+    def forward(ctx, module, record, x, masks, *params):
         eng = Engine(x.device, record)
         logits_act, feat_act = module._run(eng, x, masks)
         ctx.eng, ctx.logits_act, ctx.feat_act, ctx.params = eng, logits_act, feat_act, params
@@ -200,7 +199,7 @@ class _ClassifierFunction(torch.autograd.Function):
             gp_ = eng.param_grads.get(id(p))
             grads.append(gp_.reshape(p.shape) if gp_ is not None else None)
         ctx.eng = None
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class FogIntensityClassifier(nn.Module):
@@ -255,7 +254,8 @@ class FogIntensityClassifier(nn.Module):
             m1 = (torch.rand(N, 1, 1, 256, device=x.device) >= 0.2).float() / 0.8
             masks = (m0, m1)
         params = list(self.parameters())
-        return _ClassifierFunction.apply(self, x, masks, *params)
+        record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _ClassifierFunction.apply(self, record, x, masks, *params)
 
     def extract_features(self, x):
         with torch.no_grad():

@@ -24,8 +24,7 @@ class BranchFunction(torch.autograd.Function):
     """Outer autograd hook: one node per branch forward; the tape inside the Engine does the rest."""
 
     @staticmethod
-    def forward(ctx, module, x, *params):
-        record = any(ctx.needs_input_grad[2:])
+    def forward(ctx, module, record, x, *params):
         eng = Engine(x.device, record)
         out, holder = module._run(eng, x)
         ctx.eng, ctx.holder, ctx.params = eng, holder, params
@@ -41,7 +40,7 @@ class BranchFunction(torch.autograd.Function):
             gp = eng.param_grads.get(id(p))
             grads.append(gp.reshape(p.shape) if gp is not None else None)
         ctx.eng = None
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 class BaseDehazeModel(nn.Module):
@@ -57,7 +56,8 @@ class BaseDehazeModel(nn.Module):
         params = [p for p in self.parameters()]
         for p in params:
             H.require_cuda(p, "model parameter")
-        return BranchFunction.apply(self, x, *params)
+        record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return BranchFunction.apply(self, record, x, *params)
 
     def _run(self, eng: Engine, x: torch.Tensor):
         raise NotImplementedError

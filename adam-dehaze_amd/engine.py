@@ -207,13 +207,17 @@ class Engine:
                 L = WLayout(Cout, Cin, k, k, 0, k, 1, Cin * kk, kk)
                 plans.append((L, dict(in_s=1, out_s=1, out_o=(0, 0), dy0=pad, dx0=pad, dstep=-1, KH=k, KW=k,
                                       vgrid="out")))
-            else:               # dgrad of k4 s2 p1 conv = transposed-conv form, one launch per output parity
-                assert k == 4 and stride == 2 and pad == 1
+            else:               # dgrad of a stride-2 conv = transposed-conv form, one launch per output parity
+                assert stride == 2
                 for py in range(2):
                     for px in range(2):
-                        L = WLayout(Cout, Cin, 2, 2, (1 - py) * 4 + (1 - px), 8, 2, Cin * kk, kk)
-                        plans.append((L, dict(in_s=1, out_s=2, out_o=(py, px), dy0=py, dx0=px, dstep=-1, KH=2, KW=2,
-                                              vgrid="in")))
+                        ky0, kx0 = (py + pad) % 2, (px + pad) % 2
+                        Ty, Tx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
+                        if Ty <= 0 or Tx <= 0:
+                            continue    # no tap reaches this parity class (e.g. 1x1 stride-2): gradient is zero there
+                        L = WLayout(Cout, Cin, Ty, Tx, ky0 * k + kx0, 2 * k, 2, Cin * kk, kk)
+                        plans.append((L, dict(in_s=1, out_s=2, out_o=(py, px), dy0=(py + pad - ky0) // 2,
+                                              dx0=(px + pad - kx0) // 2, dstep=-1, KH=Ty, KW=Tx, vgrid="in")))
         else:
             assert kind == "convT" and k == 4 and stride == 2 and pad == 1
             Cin, Cout = w.shape[0], w.shape[1]
@@ -427,7 +431,8 @@ class Engine:
             plans = self._launch_plan(kind, k, stride, pad, w, "dgrad")
             gsrc = Act(g_y, Cout)
             if x.grad is None:
-                gx = self._f(x.N, x.Hh, x.Ww, _round_up(x.C, 4))
+                sparse = (kind == "conv" and stride == 2 and len(plans) < 4)
+                gx = self._f(x.N, x.Hh, x.Ww, _round_up(x.C, 4), zero=sparse)
                 self._run_gather(plans, gsrc, gx, x.C, w)
                 x.grad = gx
             else:   # accumulate in place through the epilogue's residual input

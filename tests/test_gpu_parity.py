@@ -180,7 +180,7 @@ def test_conv_forward_dgrad_wgrad_vs_oracle(N, Cin, Cout, Hh, Ww, k, stride, pad
 
     eng = Engine(torch.device(DEV), record=True)
     xa = Act(x.permute(0, 2, 3, 1).contiguous().to(DEV))
-    wd, bd = w.to(DEV), b.to(DEV)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
     o = eng.conv(xa, wd, bd, None, kind="conv", k=k, stride=stride, pad=pad, relu=False)
     out = o.t[..., :Cout].permute(0, 3, 1, 2)
     scale = float(ref.abs().max())
@@ -204,7 +204,7 @@ def test_conv_transpose_vs_oracle(N, Cin, Cout, Hh, Ww):
     (ref * gout).sum().backward()
     eng = Engine(torch.device(DEV), record=True)
     xa = Act(x.permute(0, 2, 3, 1).contiguous().to(DEV))
-    wd, bd = w.to(DEV), b.to(DEV)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
     o = eng.conv(xa, wd, bd, None, kind="convT", k=4, stride=2, pad=1, relu=False)
     assert max_abs(o.t[..., :Cout].permute(0, 3, 1, 2), ref.detach()) < 1e-4 * max(1.0, float(ref.abs().max()))
     gpad = torch.zeros(o.t.shape, device=DEV)

@@ -180,7 +180,7 @@ def test_resnet18_classifier_train_backward_vs_oracle():
     m = m.to(DEV).train()
     hazy, _, labels = R.synthetic_batch(4, 64, 96, seed=6)
     ones = (torch.ones(4, 1, 1, 512, device=DEV), torch.ones(4, 1, 1, 256, device=DEV))
-    logits, feats = CL._ClassifierFunction.apply(m, hazy.to(DEV).contiguous(), ones, *list(m.parameters()))
+    logits, feats = CL._ClassifierFunction.apply(m, True, hazy.to(DEV).contiguous(), ones, *list(m.parameters()))
     loss = L.cross_entropy3(logits, labels.to(DEV))
     loss.backward()
     # oracle: same graph with torch ops (train-mode BN)
