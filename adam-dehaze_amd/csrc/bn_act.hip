@@ -8,27 +8,35 @@
 // ---------------------------------------------------------------------------------------------
 // finalize: partials[nblk][2][NcP] -> scale/shift/mean/invstd (+ running stats)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int NcP, int C,
-                                                          double count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps, float momentum,
-                                                          float* running_mean, float* running_var, float* scale,
-                                                          float* shift, float* save_mean, float* save_invstd) {
-    __shared__ double red[2][8][32];
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int NcP, int C,
+                                                           double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* running_mean, float* running_var, float* scale,
+                                                           float* shift, float* save_mean, float* save_invstd) {
+    // 32 channels x 32 row slices per block; each thread keeps 4 independent fp64 chains in flight
+    __shared__ double red[2][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
-    double s = 0.0, q = 0.0;
+    double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
     if (c < C) {
-        for (int b = ry; b < nblk; b += 8) {
-            s += (double)partials[((size_t)b * 2 + 0) * NcP + c];
-            q += (double)partials[((size_t)b * 2 + 1) * NcP + c];
+        int b = ry;
+        for (; b + 32 < nblk; b += 64) {
+            s0 += (double)partials[((size_t)b * 2 + 0) * NcP + c];
+            q0 += (double)partials[((size_t)b * 2 + 1) * NcP + c];
+            s1 += (double)partials[((size_t)(b + 32) * 2 + 0) * NcP + c];
+            q1 += (double)partials[((size_t)(b + 32) * 2 + 1) * NcP + c];
+        }
+        for (; b < nblk; b += 32) {
+            s0 += (double)partials[((size_t)b * 2 + 0) * NcP + c];
+            q0 += (double)partials[((size_t)b * 2 + 1) * NcP + c];
         }
     }
-    red[0][ry][cx] = s;
-    red[1][ry][cx] = q;
+    red[0][ry][cx] = s0 + s1;
+    red[1][ry][cx] = q0 + q1;
     __syncthreads();
     if (ry == 0 && c < C) {
         double S = 0.0, Q = 0.0;
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 32; ++r) {
             S += red[0][r][cx];
             Q += red[1][r][cx];
         }
@@ -55,7 +63,7 @@ extern "C" int adh_bn_finalize(void* stream, const float* partials, int nblk, in
                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd) {
     if (!partials || !scale || !shift || nblk < 1 || C < 1 || NcP < C || count <= 0) return ADH_E_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(adh_ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partials, nblk,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(adh_ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)stream, partials, nblk,
                        NcP, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean,
                        save_invstd);
     return adh_check_launch();

@@ -16,121 +16,152 @@
 
 #define WG_TW 32
 
-// T = taps handled per block (consecutive linear taps from blockIdx.z*T), 4 waves share T*TN tiles.
+// T = taps handled per block (consecutive linear taps from blockIdx.z*T).
+// 512 threads: waves 0-3 contract the current pixel tile from LDS buffer `cur` on the MFMA pipe while
+// waves 4-7 stage the next tile into the other buffer (loader / consumer split, one barrier per tile).
 template <int T, int TN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const adh_conv_desc d, const ConvGeom g, float* slab,
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc d, const ConvGeom g, float* slab,
                                                             int ntiles, int KP, int nco_groups) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = 32 * TN;
     constexpr int PER = (T * TN + 3) / 4;
-    float* xs = smem;                         // [npx][32]
-    float* gs = smem + (size_t)g.npx * 32;    // [TH*32][BN]
+    const int buf_floats = g.npx * 32 + g.TH * WG_TW * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
     const int l31 = lane & 31;
     const int h = lane >> 5;
-    constexpr int NT = 256;
 
-    const int ci_tile = blockIdx.y / nco_groups;
-    const int co_grp = blockIdx.y - ci_tile * nco_groups;
+    const int ci_tile = blockIdx.x / nco_groups;
+    const int co_grp = blockIdx.x - ci_tile * nco_groups;
     const int ci0 = ci_tile * 32;
     const int co0 = co_grp * BN;
     const int tap_base = blockIdx.z * T;
 
-    f32x16 acc[PER];
-#pragma unroll
-    for (int t = 0; t < PER; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    // the T*TN output tiles (t = tap_local*TN + tn) are dealt to the 4 waves in contiguous shares of
-    // PER; LDS offsets (floats) of each tile's two operands are wave-uniform scalars
-    int aoff[PER], boff[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int t = adh_min_i(wave * PER + j, T * TN - 1);
-        const int tl = t / TN;
-        const int tap = tap_base + tl;
-        const int tty = tap / d.KW, ttx = tap - tty * d.KW;
-        const int dy = d.dy0 + tty * d.dstep_y - g.dmin_y;
-        const int dx = d.dx0 + ttx * d.dstep_x - g.dmin_x;
-        aoff[j] = (dy * g.halo_w + dx) * 32;
-        boff[j] = 32 * (t - tl * TN);
-    }
-
     const int xitems = g.npx * 8;
     const int gitems = g.TH * WG_TW * (BN / 4);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int tt = tile;
-        const int tx = tt % g.tiles_x;
-        tt /= g.tiles_x;
-        const int ty = tt % g.tiles_y;
-        const int n = tt / g.tiles_y;
-        const int vy0 = ty * g.TH, vx0 = tx * WG_TW;
-        const int iy0 = vy0 * d.in_sy + g.dmin_y;
-        const int ix0 = vx0 * d.in_sx + g.dmin_x;
-        const float* in_n = d.in + (size_t)n * d.IH * d.IW * d.in_cstride;
-        const float* g_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
-
-        __syncthreads();  // previous tile consumed
+    if (loader) {
+        // ------------------------------------------------ loader waves: global -> LDS, one tile ahead
+        const int lt = tid & 255;
+        auto stage = [&](int tile, float* xs, float* gs) {
+            int tt = tile;
+            const int tx = tt % g.tiles_x;
+            tt /= g.tiles_x;
+            const int ty = tt % g.tiles_y;
+            const int n = tt / g.tiles_y;
+            const int vy0 = ty * g.TH, vx0 = tx * WG_TW;
+            const int iy0 = vy0 * d.in_sy + g.dmin_y;
+            const int ix0 = vx0 * d.in_sx + g.dmin_x;
+            const float* in_n = d.in + (size_t)n * d.IH * d.IW * d.in_cstride;
+            const float* g_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
 #pragma unroll 4
-        for (int item = tid; item < xitems; item += NT) {
-            const int pix = item >> 3, cq = item & 7;
-            const int hy = pix / g.halo_w, hx = pix - hy * g.halo_w;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            const int ci = ci0 + cq * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW && ci < d.Cin)
-                v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)iy * d.IW + ix) * d.in_cstride + ci);
-            *reinterpret_cast<f32x4*>(xs + pix * 32 + cq * 4) = v;
-        }
-#pragma unroll 4
-        for (int item = tid; item < gitems; item += NT) {
-            const int pix = item / (BN / 4), cq = item - pix * (BN / 4);
-            const int vy = vy0 + (pix >> 5), vx = vx0 + (pix & 31);
-            const int co = co0 + cq * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (vy < d.VH && vx < d.VW && co < d.Cout) {
-                const size_t opix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
-                v = *reinterpret_cast<const f32x4*>(g_n + opix * d.out_cstride + co);
+            for (int item = lt; item < xitems; item += 256) {
+                const int pix = item >> 3, cq = item & 7;
+                const int hy = pix / g.halo_w, hx = pix - hy * g.halo_w;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                const int ci = ci0 + cq * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW && ci < d.Cin)
+                    v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)iy * d.IW + ix) * d.in_cstride + ci);
+                *reinterpret_cast<f32x4*>(xs + pix * 32 + cq * 4) = v;
             }
-            *reinterpret_cast<f32x4*>(gs + pix * BN + cq * 4) = v;
+#pragma unroll 4
+            for (int item = lt; item < gitems; item += 256) {
+                const int pix = item / (BN / 4), cq = item - pix * (BN / 4);
+                const int vy = vy0 + (pix >> 5), vx = vx0 + (pix & 31);
+                const int co = co0 + cq * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (vy < d.VH && vx < d.VW && co < d.Cout) {
+                    const size_t opix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
+                    v = *reinterpret_cast<const f32x4*>(g_n + opix * d.out_cstride + co);
+                }
+                *reinterpret_cast<f32x4*>(gs + pix * BN + cq * 4) = v;
+            }
+        };
+        if ((int)blockIdx.y < ntiles) stage(blockIdx.y, smem, smem + (size_t)g.npx * 32);
+        __syncthreads();
+        int cur = 0;
+        for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+            const int next = tile + gridDim.y;
+            if (next < ntiles) {
+                float* xn = smem + (size_t)(cur ^ 1) * buf_floats;
+                stage(next, xn, xn + (size_t)g.npx * 32);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        // ------------------------------------------------ compute waves: LDS -> MFMA
+        f32x16 acc[PER];
+#pragma unroll
+        for (int t = 0; t < PER; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // the T*TN output tiles (t = tap_local*TN + tn) are dealt to the 4 compute waves in contiguous shares
+        // of PER; LDS offsets (floats) of each tile's two operands are wave-uniform scalars
+        int aoff[PER], boff[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int t = adh_min_i(wave * PER + j, T * TN - 1);
+            const int tl = t / TN;
+            const int tap = tap_base + tl;
+            const int tty = tap / d.KW, ttx = tap - tty * d.KW;
+            const int dy = d.dy0 + tty * d.dstep_y - g.dmin_y;
+            const int dx = d.dx0 + ttx * d.dstep_x - g.dmin_x;
+            aoff[j] = (dy * g.halo_w + dx) * 32;
+            boff[j] = 32 * (t - tl * TN);
         }
         __syncthreads();
-
-        for (int r = 0; r < g.TH; ++r) {
-            const float* xrow = xs + (r * d.in_sy * g.halo_w + h * d.in_sx) * 32 + l31;
-            const float* grow = gs + (r * WG_TW + h) * BN + l31;
-#pragma unroll 2
-            for (int q = 0; q < WG_TW / 2; ++q) {
-                float a[PER], b[PER];
+        int cur = 0;
+        for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+            const float* xs = smem + (size_t)cur * buf_floats;
+            const float* gs = xs + (size_t)g.npx * 32;
+            // software-pipelined k loop (one k-step = one pixel pair): operands of step s+1 are fetched from
+            // LDS before the MFMAs of step s issue, ping-ponging two register sets
+            const float* xbase = xs + h * d.in_sx * 32 + l31;
+            const float* gbase = gs + h * BN + l31;
+            const int rowx = d.in_sy * g.halo_w * 32, qx = 2 * d.in_sx * 32;
+            const int nsteps = g.TH * (WG_TW / 2);
+            float a0[PER], b0[PER], a1[PER], b1[PER];
+            auto ld = [&](int st, float (&a)[PER], float (&b)[PER]) {
+                const int r = st >> 4, q = st & 15;
+                const float* xr = xbase + r * rowx + q * qx;
+                const float* gr = gbase + (r * WG_TW + q * 2) * BN;
 #pragma unroll
                 for (int j = 0; j < PER; ++j) {
-                    a[j] = xrow[aoff[j] + q * 2 * d.in_sx * 32];
-                    b[j] = grow[boff[j] + q * 2 * BN];
+                    a[j] = xr[aoff[j]];
+                    b[j] = gr[boff[j]];
                 }
+            };
+            ld(0, a0, b0);
+            for (int st = 0; st < nsteps; st += 2) {
+                ld(st + 1, a1, b1);
 #pragma unroll
-                for (int j = 0; j < PER; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < PER; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[j], 0, 0, 0);
+                if (st + 2 < nsteps) ld(st + 2, a0, b0);
+#pragma unroll
+                for (int j = 0; j < PER; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[j], 0, 0, 0);
             }
+            __syncthreads();
+            cur ^= 1;
         }
-    }
-
-    // partial result -> slab[split][tap][KP][NcP]
-    const int Ttot = d.KH * d.KW;
+        // partial result -> slab[split][tap][KP][NcP]
+        const int Ttot = d.KH * d.KW;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int t = wave * PER + j;
-        if (t < T * TN) {
-            const int tap = tap_base + t / TN;
-            const int tn = t - (t / TN) * TN;
-            float* base = slab + (((size_t)blockIdx.x * Ttot + tap) * KP + ci0) * d.NcP + co0 + 32 * tn + l31;
+        for (int j = 0; j < PER; ++j) {
+            const int t = wave * PER + j;
+            if (t < T * TN) {
+                const int tap = tap_base + t / TN;
+                const int tn = t - (t / TN) * TN;
+                float* base = slab + (((size_t)blockIdx.y * Ttot + tap) * KP + ci0) * d.NcP + co0 + 32 * tn + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                base[(size_t)i * d.NcP] = acc[j][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    base[(size_t)i * d.NcP] = acc[j][r];
+                }
             }
         }
     }
@@ -149,7 +180,7 @@ __host__ static int wgrad_geometry(const adh_conv_desc* d, ConvGeom* g, int TN) 
         g->halo_w = (WG_TW - 1) * d->in_sx + ex + 1;
         g->npx = g->halo_h * g->halo_w;
         const int64_t bytes = (int64_t)g->npx * 128 + (int64_t)TH * WG_TW * 32 * TN * 4;
-        if (bytes <= 80000 || TH == 1) break;
+        if (2 * bytes <= 160 * 1024 || TH == 1) break;   // two buffers in the CU's 160 KB
         TH >>= 1;
     }
     g->TH = TH;
@@ -166,15 +197,19 @@ template <int T, int TN>
 static void launch_wgrad(hipStream_t s, const adh_conv_desc* d, const ConvGeom& g, float* slab, int nsplit, int KP) {
     const int ntiles = g.tiles_x * g.tiles_y * d->N;
     const int nco_groups = d->NcP / (32 * TN);
-    const int lds = g.npx * 128 + g.TH * WG_TW * 32 * TN * 4;
-    dim3 grid(nsplit, (KP / 32) * nco_groups, (d->KH * d->KW) / T);
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, TN>), grid, dim3(256), lds, s, *d, g, slab, ntiles, KP, nco_groups);
+    const int lds = 2 * (g.npx * 128 + g.TH * WG_TW * 32 * TN * 4);
+    // x = (ci tile, co group), y = pixel split: the workgroups that re-read one pixel range run together, so the
+    // re-reads of the G / X tiles are served by L2 / Infinity Cache instead of HBM
+    dim3 grid((KP / 32) * nco_groups, nsplit, (d->KH * d->KW) / T);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, TN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, TN>), grid, dim3(512), lds, s, *d, g, slab, ntiles, KP, nco_groups);
 }
 
 static int wgrad_pick_tn(int NcP, int T) {
     const int t = NcP / 32;
     for (int tn = 4; tn >= 1; --tn)
-        if (t % tn == 0 && (T * tn + 3) / 4 <= 9) return tn;
+        if (t % tn == 0 && (T * tn + 3) / 4 <= 12) return tn;
     return 1;
 }
 
@@ -196,7 +231,7 @@ extern "C" int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab,
 #define WG_CASE(t, tn) \
     if (T == t && TN == tn) { launch_wgrad<t, tn>(s, d, g, slab, nsplit, KP); return adh_check_launch(); }
     WG_CASE(9, 4) WG_CASE(9, 3) WG_CASE(9, 2) WG_CASE(9, 1)
-    WG_CASE(16, 2) WG_CASE(16, 1)
+    WG_CASE(16, 3) WG_CASE(16, 2) WG_CASE(16, 1)
     WG_CASE(4, 4) WG_CASE(4, 3) WG_CASE(4, 2) WG_CASE(4, 1)
     WG_CASE(7, 4) WG_CASE(7, 3) WG_CASE(7, 2) WG_CASE(7, 1)
     WG_CASE(1, 4) WG_CASE(1, 3) WG_CASE(1, 2) WG_CASE(1, 1)

@@ -291,8 +291,11 @@ class Engine:
             d = self._conv_desc(x, Cin4, g_y, _round_up(gC, 4), NcP, VH, VW, gm["KH"], gm["KW"], gm["in_s"],
                                 gm["out_s"], gm["out_o"], gm["dy0"], gm["dx0"], gm["dstep"])
             ntiles_est = x.N * ((VH + 3) // 4) * ((VW + 31) // 32)
-            ygroups = (KP // 32) * max(1, NcP // 96)
-            nsplit = max(1, min(ntiles_est, 1536 // max(1, ygroups), 512))
+            T_all = gm["KH"] * gm["KW"]
+            zgroups = 7 if T_all == 49 else 1
+            groups = (KP // 32) * max(1, NcP // 96) * zgroups
+            # one 512-thread workgroup per CU is resident: aim at ~4 rounds of 256 workgroups
+            nsplit = max(1, min(ntiles_est, max(1, 1024 // groups), 512))
             T = gm["KH"] * gm["KW"]
             slab_elems = nsplit * T * KP * NcP
             # cap the slab at 1 GiB

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the individual HIP kernels at the shapes the headline config uses
+(CORUN-Complex, bs 8, 512x1024).  Dev tool: times each entry point with HIP events on the launch
+stream, `--only` filters by substring, `--iters` repeats.  Used under rocprofv3 for PMC runs.
+
+    python tools/bench_kernels.py --only conv96 --iters 5
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from adam_dehaze_amd import _hip as H          # noqa: E402
+from adam_dehaze_amd.engine import Act, Engine  # noqa: E402
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    N = args.batch
+    cases = [
+        # name, Cin, Cout, H, W, kind, k, stride, pad
+        ("conv96_full", 96, 96, 512, 1024, "conv", 3, 1, 1),
+        ("conv192_half", 192, 192, 256, 512, "conv", 3, 1, 1),
+        ("conv384_quarter", 384, 384, 128, 256, "conv", 3, 1, 1),
+        ("head192to96_full", 192, 96, 512, 1024, "conv", 3, 1, 1),
+        ("down96to192", 96, 192, 512, 1024, "conv", 4, 2, 1),
+        ("up384to96", 384, 96, 256, 512, "convT", 4, 2, 1),
+        ("stem7x7", 8, 96, 512, 1024, "conv", 7, 1, 3),
+    ]
+    for name, Cin, Cout, Hh, Ww, kind, k, stride, pad in cases:
+        if args.only and args.only not in name:
+            continue
+        eng = Engine(dev, record=False)
+        x = Act(torch.randn(N, Hh, Ww, Cin, device=dev))
+        if kind == "conv":
+            w = torch.randn(Cout, 3 if name == "stem7x7" else Cin, k, k, device=dev) * 0.05
+        else:
+            w = torch.randn(Cin, Cout, k, k, device=dev) * 0.05
+        w.requires_grad_(True)
+        o = eng.conv(x, w, None, None, kind=kind, k=k, stride=stride, pad=pad, relu=False)
+        OH, OW = o.Hh, o.Ww
+        cin_real = w.shape[1] if kind == "conv" else Cin
+        flops = 2.0 * N * OH * OW * k * k * cin_real * Cout if kind == "conv" else 2.0 * N * Hh * Ww * 16 * Cin * Cout
+        out_t = o.t
+
+        def fwd():
+            eng._run_gather(eng._launch_plan(kind, k, stride, pad, w, "fwd"), x, out_t, Cout, w)
+
+        g = torch.randn_like(out_t)
+        gsrc = Act(g, Cout)
+        gx = torch.empty(N, Hh, Ww, Cin, device=dev)
+
+        def dgrad():
+            eng._run_gather(eng._launch_plan(kind, k, stride, pad, w, "dgrad"), gsrc, gx, Cin, w)
+
+        def wgrad():
+            eng._wgrad(eng._launch_plan(kind, k, stride, pad, w, "fwd"), x, g, Cout, w)
+
+        for tag, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+            if name == "stem7x7" and tag == "dgrad":
+                continue
+            ms = timeit(fn, args.iters)
+            print(f"{name:18s} {tag:6s} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s ({flops / 1e9:.0f} GFLOP)", flush=True)
+
+    if not args.only or "bn" in args.only:
+        P, Cc = N * 512 * 1024, 96
+        y = torch.randn(N, 512, 1024, Cc, device=dev)
+        out = torch.empty_like(y)
+        sc = torch.ones(Cc, device=dev)
+        sh = torch.zeros(Cc, device=dev)
+
+        def bn_apply():
+            H.call("adh_bn_apply", y.data_ptr(), Cc, sc.data_ptr(), sh.data_ptr(), None, 0, 1, out.data_ptr(), Cc, P, Cc)
+        ms = timeit(bn_apply, args.iters)
+        print(f"bn_apply 96ch full  {ms:8.3f} ms  {2 * y.numel() * 4 / ms / 1e9:7.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()
