@@ -67,8 +67,19 @@ class Seq(nn.ModuleDict):
 class ConvBlock(nn.Module):
     """Conv2d(bias = not use_bn) -> BatchNorm2d -> ReLU|None   (base_model.py:4-24)."""
 
-    def __init__(self, cin, cout, kernel_size=3, stride=1, padding=1, use_bn=True, relu=True):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, use_bn=True, activation="relu",
+                 relu=None):
+        """`activation`: the reference passes an nn.ReLU instance or None (base_model.py:7-8); 'relu' / None /
+        an nn.ReLU are accepted, anything else is not on the path."""
         super().__init__()
+        cin, cout = in_channels, out_channels
+        if relu is None:
+            if activation is None:
+                relu = False
+            elif activation == "relu" or isinstance(activation, nn.ReLU):
+                relu = True
+            else:
+                raise ValueError(f"unsupported activation for the HIP ConvBlock: {activation!r}")
         self.k, self.stride, self.padding, self.relu = kernel_size, stride, padding, relu
         items = [(0, ConvParams(cin, cout, kernel_size, bias=not use_bn))]
         if use_bn:

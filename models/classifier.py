@@ -1,0 +1,2 @@
+"""models/classifier.py of the reference -> adam-dehaze_amd (HIP engine)."""
+from adam_dehaze_amd.classifier import FogIntensityClassifier, create_classifier  # noqa: F401
