@@ -38,6 +38,7 @@ struct ConvGeom {
     int KC, KQ_log2;        // channels per LDS chunk, log2(KC/4)
     int KQtot;              // padded Cin / 4
     int TH;                 // tile rows (8 for forward)
+    int xp;                 // wgrad: floats per staged input pixel (32, or Cin alloc (8) in packed small-Cin mode)
 };
 
 __device__ __forceinline__ float wave_sum(float v) {

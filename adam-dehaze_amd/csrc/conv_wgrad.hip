@@ -25,7 +25,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = 32 * TN;
     constexpr int PER = (T * TN + 3) / 4;
-    const int buf_floats = g.npx * 32 + g.TH * WG_TW * BN;
+    const int XP = g.xp;
+    const int buf_floats = g.npx * XP + 32 + g.TH * WG_TW * BN;   // +32: packed mode reads up to 3 pixels past a row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -40,7 +41,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc 
     const int co0 = co_grp * BN;
     const int tap_base = blockIdx.z * T;
 
-    const int xitems = g.npx * 8;
+    const int XQ = XP / 4;
+    const int xitems = g.npx * XQ;
     const int gitems = g.TH * WG_TW * (BN / 4);
 
     if (loader) {
@@ -59,14 +61,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc 
             const float* g_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
 #pragma unroll 4
             for (int item = lt; item < xitems; item += 256) {
-                const int pix = item >> 3, cq = item & 7;
+                const int pix = item / XQ, cq = item - pix * XQ;
                 const int hy = pix / g.halo_w, hx = pix - hy * g.halo_w;
                 const int iy = iy0 + hy, ix = ix0 + hx;
                 const int ci = ci0 + cq * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW && ci < d.Cin)
                     v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)iy * d.IW + ix) * d.in_cstride + ci);
-                *reinterpret_cast<f32x4*>(xs + pix * 32 + cq * 4) = v;
+                *reinterpret_cast<f32x4*>(xs + pix * XP + cq * 4) = v;
             }
 #pragma unroll 4
             for (int item = lt; item < gitems; item += 256) {
@@ -81,14 +83,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc 
                 *reinterpret_cast<f32x4*>(gs + pix * BN + cq * 4) = v;
             }
         };
-        if ((int)blockIdx.y < ntiles) stage(blockIdx.y, smem, smem + (size_t)g.npx * 32);
+        if ((int)blockIdx.y < ntiles) stage(blockIdx.y, smem, smem + (size_t)g.npx * XP + 32);
         __syncthreads();
         int cur = 0;
         for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
             const int next = tile + gridDim.y;
             if (next < ntiles) {
                 float* xn = smem + (size_t)(cur ^ 1) * buf_floats;
-                stage(next, xn, xn + (size_t)g.npx * 32);
+                stage(next, xn, xn + (size_t)g.npx * XP + 32);
             }
             __syncthreads();
             cur ^= 1;
@@ -111,19 +113,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc 
             const int tty = tap / d.KW, ttx = tap - tty * d.KW;
             const int dy = d.dy0 + tty * d.dstep_y - g.dmin_y;
             const int dx = d.dx0 + ttx * d.dstep_x - g.dmin_x;
-            aoff[j] = (dy * g.halo_w + dx) * 32;
+            aoff[j] = (dy * g.halo_w + dx) * XP;
             boff[j] = 32 * (t - tl * TN);
         }
         __syncthreads();
         int cur = 0;
         for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
             const float* xs = smem + (size_t)cur * buf_floats;
-            const float* gs = xs + (size_t)g.npx * 32;
+            const float* gs = xs + (size_t)g.npx * XP + 32;
             // software-pipelined k loop (one k-step = one pixel pair): operands of step s+1 are fetched from
             // LDS before the MFMAs of step s issue, ping-ponging two register sets
-            const float* xbase = xs + h * d.in_sx * 32 + l31;
+            const float* xbase = xs + h * d.in_sx * XP + l31;
             const float* gbase = gs + h * BN + l31;
-            const int rowx = d.in_sy * g.halo_w * 32, qx = 2 * d.in_sx * 32;
+            const int rowx = d.in_sy * g.halo_w * XP, qx = 2 * d.in_sx * XP;
             const int nsteps = g.TH * (WG_TW / 2);
             float a0[PER], b0[PER], a1[PER], b1[PER];
             auto ld = [&](int st, float (&a)[PER], float (&b)[PER]) {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc 
     }
 }
 
-__host__ static int wgrad_geometry(const adh_conv_desc* d, ConvGeom* g, int TN) {
+__host__ static int wgrad_geometry(const adh_conv_desc* d, ConvGeom* g, int TN, int xp) {
     if (!d || d->KH < 1 || d->KW < 1) return ADH_E_ARG;
     if (d->Cin % 4 != 0 || d->in_cstride % 4 != 0 || d->Cout % 4 != 0 || d->out_cstride % 4 != 0) return ADH_E_ARG;
     g->dmin_y = adh_tap_min(d->dy0, d->dstep_y, d->KH);
@@ -177,9 +179,9 @@ __host__ static int wgrad_geometry(const adh_conv_desc* d, ConvGeom* g, int TN) 
     int TH = 4;
     for (;;) {
         g->halo_h = (TH - 1) * d->in_sy + ey + 1;
-        g->halo_w = (WG_TW - 1) * d->in_sx + ex + 1;
+        g->halo_w = (WG_TW - 1) * d->in_sx + ex + 1 + (32 / xp - 1);   // packed mode: an i-tile spans 32/xp pixels
         g->npx = g->halo_h * g->halo_w;
-        const int64_t bytes = (int64_t)g->npx * 128 + (int64_t)TH * WG_TW * 32 * TN * 4;
+        const int64_t bytes = (int64_t)g->npx * xp * 4 + 128 + (int64_t)TH * WG_TW * 32 * TN * 4;
         if (2 * bytes <= 160 * 1024 || TH == 1) break;   // two buffers in the CU's 160 KB
         TH >>= 1;
     }
@@ -190,6 +192,7 @@ __host__ static int wgrad_geometry(const adh_conv_desc* d, ConvGeom* g, int TN) 
     g->KC = 32;
     g->KQ_log2 = 3;
     g->KQtot = 0;
+    g->xp = xp;
     return ADH_OK;
 }
 
@@ -197,7 +200,7 @@ template <int T, int TN>
 static void launch_wgrad(hipStream_t s, const adh_conv_desc* d, const ConvGeom& g, float* slab, int nsplit, int KP) {
     const int ntiles = g.tiles_x * g.tiles_y * d->N;
     const int nco_groups = d->NcP / (32 * TN);
-    const int lds = 2 * (g.npx * 128 + g.TH * WG_TW * 32 * TN * 4);
+    const int lds = 2 * (g.npx * g.xp * 4 + 128 + g.TH * WG_TW * 32 * TN * 4);
     // x = (ci tile, co group), y = pixel split: the workgroups that re-read one pixel range run together, so the
     // re-reads of the G / X tiles are served by L2 / Infinity Cache instead of HBM
     dim3 grid((KP / 32) * nco_groups, nsplit, (d->KH * d->KW) / T);
@@ -219,11 +222,14 @@ extern "C" int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab,
     const int Ttot = d->KH * d->KW;
     int T;
     if (Ttot == 9 || Ttot == 16 || Ttot == 4 || Ttot == 1) T = Ttot;
-    else if (Ttot == 49) T = 7;   // one kernel row per block (blockIdx.z)
+    else if (Ttot == 49 || Ttot == 14) T = 7;   // one kernel row (or packed column group) per block (blockIdx.z)
     else return ADH_E_UNSUPPORTED;
+    // packed small-Cin mode (7x7 stems): the 32-wide MFMA row tile spans 4 adjacent pixels x 8 channels, so a
+    // "tap" is (ky, group of 4 kx) and dstep_x == 4; see adh_wgrad_reduce_packed for the unpacking
+    const bool packed = (d->dstep_x == 4 && d->Cin == 8 && d->in_sx == 1);
     const int TN = wgrad_pick_tn(d->NcP, T);
     ConvGeom g;
-    int rc = wgrad_geometry(d, &g, TN);
+    int rc = wgrad_geometry(d, &g, TN, packed ? 8 : 32);
     if (rc) return rc;
     if ((d->VH - 1) * d->out_sy + d->out_oy >= d->OH || (d->VW - 1) * d->out_sx + d->out_ox >= d->OW) return ADH_E_ARG;
     const int KP = adh_round_up(d->Cin, 32);
@@ -276,5 +282,43 @@ extern "C" int adh_wgrad_reduce(void* stream, const float* slab, int nsplit, int
     const int blocks = adh_min_i(adh_ceil_div(total, 256), 8192);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slab, nsplit, KP, NcP, *L,
                        dst, accumulate);
+    return adh_check_launch();
+}
+
+// Packed small-Cin slabs: slab[s][tap=(ky*KWg+kxg)][i=(kxl*8+ci)][NcP] -> dst OIHW [Cout][Cin][KH][KW]
+__global__ void wgrad_reduce_packed_kernel(const float* __restrict__ slab, int nsplit, int NcP, int Cin, int KH, int KW,
+                                           int Cout, float* __restrict__ dst, int accumulate) {
+    const int KWg = (KW + 3) / 4;
+    const int64_t total = (int64_t)Cout * Cin * KH * KW;
+    const int64_t split_stride = (int64_t)KH * KWg * 32 * NcP;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int kx = (int)(idx % KW);
+        int64_t r = idx / KW;
+        const int ky = (int)(r % KH);
+        r /= KH;
+        const int ci = (int)(r % Cin);
+        const int co = (int)(r / Cin);
+        const int tap = ky * KWg + (kx >> 2);
+        const int i = (kx & 3) * 8 + ci;
+        const float* p = slab + ((int64_t)tap * 32 + i) * NcP + co;
+        float s0 = 0.f, s1 = 0.f;
+        int s = 0;
+        for (; s + 2 <= nsplit; s += 2) {
+            s0 += p[(int64_t)s * split_stride];
+            s1 += p[(int64_t)(s + 1) * split_stride];
+        }
+        if (s < nsplit) s0 += p[(int64_t)s * split_stride];
+        const float sum = s0 + s1;
+        dst[idx] = accumulate ? dst[idx] + sum : sum;
+    }
+}
+
+extern "C" int adh_wgrad_reduce_packed(void* stream, const float* slab, int nsplit, int NcP, int Cin, int KH, int KW, int Cout,
+                                       float* dst, int accumulate) {
+    if (!slab || !dst || nsplit < 1 || Cin < 1 || Cin > 8) return ADH_E_ARG;
+    const int64_t total = (int64_t)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(wgrad_reduce_packed_kernel, dim3(adh_min_i(adh_ceil_div(total, 256), 4096)), dim3(256), 0,
+                       (hipStream_t)stream, slab, nsplit, NcP, Cin, KH, KW, Cout, dst, accumulate);
     return adh_check_launch();
 }

@@ -107,11 +107,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
+    if local_rank >= torch.cuda.device_count():   # rehearsal of the N>1 path on a single-GPU box
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("ADH_DIST_BACKEND", "nccl")   # nccl = RCCL over xGMI; gloo only for single-GPU rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import adam_dehaze_amd as A
     from adam_dehaze_amd import _hip as H

@@ -98,6 +98,12 @@ int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab, int nsplit
 int adh_wgrad_reduce(void* stream, const float* slab, int nsplit, int KP, int NcP,
                      const adh_wlayout* L, float* dst, int accumulate);
 
+/* Packed small-Cin weight gradient (7x7 stems, Cin <= 8 stored with cstride 8): call adh_conv_wgrad with
+ * KW = ceil(kw/4), dstep_x = 4, Cin = 8 -- the 32-wide MFMA row tile then spans 4 adjacent pixels x 8
+ * channels -- and unpack slab[s][ky*KWg + kxg][kxl*8 + ci][NcP] into OIHW with this call. */
+int adh_wgrad_reduce_packed(void* stream, const float* slab, int nsplit, int NcP, int Cin, int KH, int KW, int Cout,
+                            float* dst, int accumulate);
+
 /* ---- BatchNorm2d + activation (base_model.py:15-19,36-41; eps 1e-5, momentum 0.1) ---------- */
 /* reduce `nblk` partial rows [2][NcP] -> batch mean / biased var over `count` elements per channel;
  * writes scale = gamma*invstd, shift = beta - mean*scale, save_mean, save_invstd and updates
