@@ -97,6 +97,12 @@ _SIGNATURES = {
     "adh_l1_bwd": [vp, vp, vp, i64, f32, vp, vp],
     "adh_mse_bwd": [vp, vp, vp, i64, f32, vp, vp],
     "adh_cross_entropy3": [vp, vp, vp, i32, vp, vp],
+    "adh_lpips_s2d": [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp],
+    "adh_lpips_s2d_bwd": [vp, vp, i32, i32, i32, vp, i32, i32, vp],
+    "adh_lpips_layer": [vp, vp, vp, vp, i32, i32, i32, vp, i32],
+    "adh_lpips_layer_num_blocks": [i32],
+    "adh_lpips_layer_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "adh_rows_sum": [vp, vp, i32, i32, f32, vp, i32],
     "adh_adam_step": [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32],
     "adh_add_inplace": [vp, vp, vp, i64],
     "adh_axpby_strided": [vp, vp, i32, vp, i32, i64, i32, f32, f32],
@@ -112,7 +118,7 @@ _SIGNATURES = {
 # functions that return a count / size rather than a status code
 _VALUE_FUNCS = {"adh_version", "adh_conv_lds_bytes", "adh_conv_num_blocks", "adh_bn_bwd_num_blocks",
                 "adh_cbam_pool_num_blocks", "adh_cbam_bwd_b_num_blocks", "adh_head_blend_bwd_num_blocks",
-                "adh_reduce_num_blocks"}
+                "adh_reduce_num_blocks", "adh_lpips_layer_num_blocks"}
 
 _ERRORS = {-1: "ADH_E_ARG (bad argument: shape / alignment / null pointer)",
            -2: "ADH_E_LAUNCH (hip kernel launch failed)",

@@ -2,10 +2,9 @@
 
 `DehazingLoss` = 1.0*L1 + 0.1*content(VGG16 taps) + 0.1*LPIPS(alex); `JointLoss` adds 0.2*CE
 (+ 0.5 * detection, always 0 in the drivers).  Forward signatures and returned dict keys follow
-loss.py:125-162 and :179-224.  The third-party feature networks (VGG16 / LPIPS-AlexNet) need
-pretrained weights that are not available offline; they are attached with `attach_vgg16` /
-`attach_lpips` (state_dicts with torchvision / lpips key names).  Until then the corresponding terms
-are reported as 0 and excluded, which the returned dict makes explicit (`'content_available'`).
+loss.py:125-162 and :179-224.  The third-party feature networks (VGG16 / LPIPS-AlexNet) are built here
+with torchvision / lpips parameter names; their pretrained weights cannot be downloaded offline, so they
+start randomly initialised (load real ones with load_state_dict).
 """
 from __future__ import annotations
 
@@ -225,22 +224,165 @@ class ContentLoss(nn.Module):
         return _ContentFn.apply(self, x, target, *params)
 
 
+class _ScalingLayer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("shift", torch.tensor([-0.030, -0.088, -0.188]).view(1, 3, 1, 1))
+        self.register_buffer("scale", torch.tensor([0.458, 0.448, 0.450]).view(1, 3, 1, 1))
+
+
+class _NetLin(nn.Module):
+    """lpips NetLinLayer: Dropout (identity in eval) + 1x1 conv without bias at index 1."""
+
+    def __init__(self, cin):
+        super().__init__()
+        from .layers import ConvParams, Seq
+        self.model = Seq([(1, ConvParams(cin, 1, 1, bias=False))])
+
+
+class _AlexSlices(nn.Module):
+    def __init__(self):
+        super().__init__()
+        from .layers import ConvParams, Seq
+        self.slice1 = Seq([(0, ConvParams(3, 64, 11, bias=True))])
+        self.slice2 = Seq([(3, ConvParams(64, 192, 5, bias=True))])
+        self.slice3 = Seq([(6, ConvParams(192, 384, 3, bias=True))])
+        self.slice4 = Seq([(8, ConvParams(384, 256, 3, bias=True))])
+        self.slice5 = Seq([(10, ConvParams(256, 256, 3, bias=True))])
+
+
+class _LPIPSAlex(nn.Module):
+    """lpips.LPIPS(net='alex') parameter layout: net.slice{1..5}.{idx}.*, scaling_layer.{shift,scale},
+    lin{k}.model.1.weight and lins.{k}.model.1.weight (the same tensors under both names, as lpips has)."""
+
+    CHNS = (64, 192, 384, 256, 256)
+
+    def __init__(self):
+        super().__init__()
+        self.scaling_layer = _ScalingLayer()
+        self.net = _AlexSlices()
+        lins = []
+        for k, c in enumerate(self.CHNS):
+            lin = _NetLin(c)
+            setattr(self, f"lin{k}", lin)
+            lins.append(lin)
+        self.lins = nn.ModuleList(lins)
+        for p in self.parameters():
+            p.requires_grad = False
+
+
+class _LPIPSFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, record, pred, target):
+        from .engine import Engine
+        eng_t = Engine(pred.device, False)
+        feats_t = module._features(eng_t, target.contiguous(), {})
+        eng = Engine(pred.device, record)
+        holder = {}
+        feats_p = module._features(eng, pred.contiguous(), holder)
+        N = pred.shape[0]
+        val = torch.empty(N, device=pred.device, dtype=torch.float32)
+        lin = module.loss_fn
+        taps = []
+        for k, (fp, ft) in enumerate(zip(feats_p, feats_t)):
+            w = getattr(lin, f"lin{k}").model.at(1).weight
+            HW, Cc = fp.Hh * fp.Ww, fp.C
+            nblk = H.value("adh_lpips_layer_num_blocks", HW)
+            partial = torch.empty((N, nblk), device=pred.device, dtype=torch.float32)
+            H.call("adh_lpips_layer", fp.t.data_ptr(), ft.t.data_ptr(), w.data_ptr(), N, HW, Cc, partial.data_ptr(), nblk)
+            H.call("adh_rows_sum", partial.data_ptr(), N, nblk, 1.0 / HW, val.data_ptr(), 1 if k > 0 else 0)
+            taps.append((fp, ft, w))
+        ctx.eng, ctx.holder, ctx.taps, ctx.N = eng, holder, taps, N
+        return val.view(N, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        eng = ctx.eng
+        gv = g.contiguous().view(-1)
+        for fp, ft, w in ctx.taps:
+            if not fp.needs_grad:
+                continue
+            ga = torch.empty_like(fp.t)
+            H.call("adh_lpips_layer_bwd", fp.t.data_ptr(), ft.t.data_ptr(), w.data_ptr(), gv.data_ptr(), ctx.N,
+                   fp.Hh * fp.Ww, fp.C, ga.data_ptr())
+            eng.accum(fp, ga)
+        eng.backward()
+        gx = ctx.holder.get("gx")
+        ctx.eng = None
+        return None, None, gx, None
+
+
+class PerceptualLoss(nn.Module):
+    """Perceptual loss based on LPIPS (loss.py:86-108): lpips.LPIPS(net='alex') on 2x-1 inputs -> [N,1,1,1].
+    AlexNet's 11x11 stride-4 stem runs as a 3x3 stride-1 MFMA conv on a space-to-depth(4) image.  Weights use
+    lpips' own key names (load a real checkpoint with load_state_dict); extractor and lin layers are frozen."""
+
+    def __init__(self, net="alex"):
+        super().__init__()
+        if net != "alex":
+            raise ValueError(f"Unsupported LPIPS net: {net}")
+        self.loss_fn = _LPIPSAlex()
+
+    def _features(self, eng, img, holder):
+        import ctypes as C
+        from .engine import Act
+        lp = self.loss_fn
+        N, _, Hh, Ww = img.shape
+        OH, OW = (Hh + 4 - 11) // 4 + 1, (Ww + 4 - 11) // 4 + 1
+        shift = lp.scaling_layer.shift.view(-1).tolist()
+        scale = lp.scaling_layer.scale.view(-1).tolist()
+        a = [2.0 / s_ for s_ in scale]                       # ((2x-1) - shift)/scale = x*a + b
+        b = [(-1.0 - sh) / s_ for sh, s_ in zip(shift, scale)]
+        a3, b3 = (C.c_float * 3)(*a), (C.c_float * 3)(*b)
+        s2d = eng._f(N, OH + 2, OW + 2, 48)
+        H.call("adh_lpips_s2d", img.data_ptr(), N, Hh, Ww, a3, b3, OH + 2, OW + 2, s2d.data_ptr())
+        x = Act(s2d, 48, needs_grad=eng.record)
+        if eng.record:
+            def bwd():
+                g = x.grad
+                x.grad = None
+                if g is None:
+                    return
+                gx = torch.empty_like(img)
+                H.call("adh_lpips_s2d_bwd", g.contiguous().data_ptr(), N, Hh, Ww, a3, OH + 2, OW + 2, gx.data_ptr())
+                holder["gx"] = gx
+            eng.tape.append(bwd)
+        # conv1 11x11 s4 p2 as a 3x3 s1 conv over 48 = (by,bx,c) channels: W'[co][(by*4+bx)*3+c][ty][tx] = W[co][c][4ty+by][4tx+bx]
+        c1 = lp.net.slice1.at(0)
+        w = torch.zeros(64, 3, 12, 12, device=img.device)
+        w[:, :, :11, :11] = c1.weight
+        w1 = w.view(64, 3, 3, 4, 3, 4).permute(0, 3, 5, 1, 2, 4).reshape(64, 48, 3, 3).contiguous()
+        feats = []
+        h = eng.conv(x, w1, c1.bias, None, k=3, stride=1, pad=0, relu=True)
+        feats.append(h)
+        h = eng.maxpool(h, 3, 2, 0)
+        c2 = lp.net.slice2.at(3)
+        h = eng.conv(h, c2.weight, c2.bias, None, k=5, stride=1, pad=2, relu=True)
+        feats.append(h)
+        h = eng.maxpool(h, 3, 2, 0)
+        for sl, idx in ((lp.net.slice3, 6), (lp.net.slice4, 8), (lp.net.slice5, 10)):
+            c = sl.at(idx)
+            h = eng.conv(h, c.weight, c.bias, None, k=3, stride=1, pad=1, relu=True)
+            feats.append(h)
+        return feats
+
+    def forward(self, x, target):
+        H.require_cuda(x, "prediction")
+        H.require_cuda(target, "target")
+        record = torch.is_grad_enabled() and x.requires_grad
+        return _LPIPSFn.apply(self, record, x, target)
+
+
 class DehazingLoss(nn.Module):
     """Combined loss for image dehazing (loss.py:110-162)."""
 
-    def __init__(self, lambda_l1=1.0, lambda_content=0.1, lambda_perceptual=0.1):
+    def __init__(self, lambda_l1=1.0, lambda_content=0.1, lambda_perceptual=0.1, content=True, perceptual=True):
+        """`content` / `perceptual` = False drop the VGG16 / LPIPS terms (their pretrained weights cannot be
+        downloaded here: the extractors are randomly initialised until a checkpoint is loaded)."""
         super().__init__()
         self.lambda_l1, self.lambda_content, self.lambda_perceptual = lambda_l1, lambda_content, lambda_perceptual
-        self.content_loss = None      # set by attach_vgg16
-        self.perceptual_loss = None   # set by attach_lpips
-
-    def attach_vgg16(self, module: nn.Module):
-        self.content_loss = module
-        return self
-
-    def attach_lpips(self, module: nn.Module):
-        self.perceptual_loss = module
-        return self
+        self.content_loss = ContentLoss() if content else None
+        self.perceptual_loss = PerceptualLoss() if perceptual else None
 
     def forward(self, pred, target):
         l1 = l1_loss(pred, target)

@@ -234,6 +234,23 @@ int adh_mse_bwd(void* stream, const float* a, const float* b, int64_t n, float g
 /* cross entropy over 3 classes, mean reduction: loss scalar + dlogits[n][3] (scaled by 1/N) */
 int adh_cross_entropy3(void* stream, const float* logits, const int64_t* labels, int N, float* loss, float* dlogits);
 
+/* ---- LPIPS (lpips.LPIPS(net='alex'), training/loss.py:86-108) --------------------------------------- */
+/* Fused input stage: v = img*a_c + b_c (the [-1,1] rescale and lpips' ScalingLayer), zero padded by 2 and
+ * rearranged space-to-depth(4): out[n][r][q][(by*4+bx)*3 + c] = v[c][4r+by-2][4q+bx-2], out is
+ * [N][OH+2][OW+2][48] with OH = (H+4-11)/4+1 -- AlexNet's 11x11 stride-4 conv becomes a 3x3 stride-1 conv. */
+int adh_lpips_s2d(void* stream, const float* img, int N, int H, int W, const float* a3, const float* b3, int OHp, int OWp,
+                  float* out);
+int adh_lpips_s2d_bwd(void* stream, const float* g, int N, int H, int W, const float* a3, int OHp, int OWp, float* g_img);
+/* one LPIPS tap: val[n] += (1/HW) * sum_p sum_c w[c] * (a/(|a|+eps) - b/(|b|+eps))^2 ; partial[n][nblk] */
+int adh_lpips_layer(void* stream, const float* fa, const float* fb, const float* w, int N, int HW, int C, float* partial,
+                    int nblk);
+int adh_lpips_layer_num_blocks(int HW);
+/* gradient wrt fa given the upstream per-image cotangent g_val[n] (already including any scalar factor) */
+int adh_lpips_layer_bwd(void* stream, const float* fa, const float* fb, const float* w, const float* g_val, int N, int HW,
+                        int C, float* g_fa);
+/* out[n] = sum_b partial[n][b] * scale (+ out[n] if accumulate) */
+int adh_rows_sum(void* stream, const float* partial, int N, int nblk, float scale, float* out, int accumulate);
+
 /* ---- optimiser (training/train_joint.py:86-90: Adam, weight_decay 1e-4) ------------------------------ */
 /* `repeats` consecutive Adam updates with the same gradient and shared state (the reference lists every
  * branch parameter twice, train_joint.py:81-84); step = count before the call. */

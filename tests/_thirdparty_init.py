@@ -4,7 +4,7 @@ import math
 
 import torch
 
-from oracle.ref_cpu import VGG16_CFG, ALEX_CFG, DENSENET121_BLOCKS
+from oracle.ref_cpu import VGG16_CFG, ALEX_CFG, ALEX_SLICE_OF, DENSENET121_BLOCKS
 
 
 def _conv(sd, name, cout, cin, k, g, bias=False):
@@ -100,10 +100,13 @@ def lpips_alex_sd(seed=0, prefix="loss_fn."):
             idx += 1
         else:
             c, k, _, _ = v
-            _conv(sd, f"{prefix}net.features.{idx}", c, cin, k, g, bias=True)
+            _conv(sd, f"{prefix}net.{ALEX_SLICE_OF[idx]}", c, cin, k, g, bias=True)
             cin = c
             chans.append(c)
             idx += 2
     for k, c in enumerate(chans):
         sd[f"{prefix}lin{k}.model.1.weight"] = torch.rand(1, c, 1, 1, generator=g) / c
+        sd[f"{prefix}lins.{k}.model.1.weight"] = sd[f"{prefix}lin{k}.model.1.weight"]   # lpips registers both names
+    sd[f"{prefix}scaling_layer.shift"] = torch.tensor([-0.030, -0.088, -0.188]).view(1, 3, 1, 1)
+    sd[f"{prefix}scaling_layer.scale"] = torch.tensor([0.458, 0.448, 0.450]).view(1, 3, 1, 1)
     return sd

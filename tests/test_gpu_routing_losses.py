@@ -14,7 +14,7 @@ from adam_dehaze_amd import loss as L
 from adam_dehaze_amd import routing as RT
 from adam_dehaze_amd.optim import Adam
 from oracle import ref_cpu as R
-from tests._thirdparty_init import densenet121_sd, resnet18_sd, vgg16_sd
+from tests._thirdparty_init import densenet121_sd, lpips_alex_sd, resnet18_sd, vgg16_sd
 from tests._util import load_golden, max_abs, rel_err, sub_sd, t
 
 pytestmark = pytest.mark.gpu
@@ -260,6 +260,46 @@ def test_content_loss_vs_oracle():
     assert rel_err(p.grad, pr.grad) < 2e-3
 
 
+def test_perceptual_loss_lpips_alex_vs_oracle():
+    sd = lpips_alex_sd(5)
+    pl = L.PerceptualLoss()
+    pl.load_state_dict(sd, strict=True)
+    pl = pl.to(DEV)
+    g = torch.Generator().manual_seed(4)
+    pred = torch.rand(2, 3, 67, 99, generator=g)     # sizes that are not multiples of the stem stride
+    target = torch.rand(2, 3, 67, 99, generator=g)
+    pr = pred.clone().requires_grad_(True)
+    ref = R.perceptual_loss(pr, target, sd)
+    ref.mean().backward()
+    p = pred.clone().to(DEV).requires_grad_(True)
+    val = pl(p, target.to(DEV))
+    assert val.shape == (2, 1, 1, 1)
+    assert rel_err(val, ref.detach()) < 1e-3
+    val.mean().backward()
+    assert rel_err(p.grad, pr.grad) < 5e-3
+    with torch.no_grad():
+        assert float(pl(p, p).abs().max()) == 0.0
+
+
+def test_dehazing_loss_full_vs_oracle():
+    crit = L.DehazingLoss().to(DEV)
+    vgg_sd = {k: v.detach().cpu() for k, v in crit.content_loss.state_dict().items()}
+    lp_sd = {k: v.detach().cpu() for k, v in crit.perceptual_loss.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    pred = torch.rand(2, 3, 64, 64, generator=g)
+    target = torch.rand(2, 3, 64, 64, generator=g)
+    pr = pred.clone().requires_grad_(True)
+    ref, comps_r = R.dehazing_loss(pr, target, vgg_sd, lp_sd)
+    ref.backward()
+    p = pred.clone().to(DEV).requires_grad_(True)
+    total, comps = crit(p, target.to(DEV))
+    assert set(comps) == {"l1", "content", "perceptual", "total"}
+    for k in ("l1", "content", "perceptual", "total"):
+        assert abs(float(comps[k].detach()) - float(comps_r[k].detach())) < 1e-3 * max(1.0, abs(float(comps_r[k]))), k
+    total.backward()
+    assert rel_err(p.grad, pr.grad) < 5e-3
+
+
 def test_joint_loss_dict_keys_and_values():
     cfg = {"joint_training": {"lambda_dehazing": 1.0, "lambda_classification": 0.2, "lambda_detection": 0.5}}
     crit = L.get_joint_loss(cfg).to(DEV)
@@ -271,5 +311,7 @@ def test_joint_loss_dict_keys_and_values():
     total, d = crit(pred.to(DEV), target.to(DEV), logits.to(DEV), labels.to(DEV))
     assert set(d) == {"dehazing", "classification", "detection", "total", "dehazing_components"}
     assert set(d["dehazing_components"]) == {"l1", "content", "perceptual", "total"}
-    ref, _ = R.joint_loss(pred, target, logits, labels)
-    assert abs(float(total) - float(ref)) < 1e-5
+    vgg_sd = {k: v.detach().cpu() for k, v in crit.dehazing_loss.content_loss.state_dict().items()}
+    lp_sd = {k: v.detach().cpu() for k, v in crit.dehazing_loss.perceptual_loss.state_dict().items()}
+    ref, _ = R.joint_loss(pred, target, logits, labels, vgg_sd, lp_sd)
+    assert abs(float(total) - float(ref)) < 1e-3 * max(1.0, float(ref))

