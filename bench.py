@@ -88,6 +88,99 @@ def psnr_check(model, device):
     return R.psnr(out, ref), float((out - ref).abs().max())
 
 
+def other_workloads(args, rank, world, device):
+    """The other BASELINE.json configs (secondary measurements; same timing protocol, one JSON line)."""
+    import warnings
+    import torch.distributed as dist
+    import adam_dehaze_amd as A
+    from adam_dehaze_amd import train as T
+    from adam_dehaze_amd.classifier import FogIntensityClassifier
+    from adam_dehaze_amd.loss import DehazingLoss, l1_loss
+    from adam_dehaze_amd.optim import Adam
+    from adam_dehaze_amd.parallel import GradientSynchronizer
+    from adam_dehaze_amd.routing import HardRouter
+    warnings.simplefilter("ignore")
+    wl = args.workload
+    bs = args.batch
+    if wl == "config2":      # HDEN classify + hard route -> CORUN-Light forward, bs 8, 512x1024 (eval)
+        clf = FogIntensityClassifier("densenet121", 3, pretrained=False).to(device).eval()
+        models = {"low": A.LightweightDehazeModel(), "medium": A.MediumIntensityDehazeModel(),
+                  "high": A.HighIntensityDehazeModel()}
+        router = HardRouter(models, clf, device=str(device)).to(device).eval()
+        hazy, _ = synthetic_batch(bs, args.height, args.width, seed=42 + rank)
+        hazy = hazy.to(device)
+        labels = torch.zeros(bs, dtype=torch.int64, device=device)   # all-"low" labels (SURVEY.md 8d config 2)
+
+        def step():
+            with torch.no_grad():
+                logits, _ = clf(hazy)            # HDEN forward (its argmax is what an unlabeled run would route by)
+                out, _ = router(hazy, labels)
+            return out.sum()
+        desc = "HDEN DenseNet121 classify + hard route (all-low labels) -> CORUN-Light forward (eval)"
+    elif wl == "config3" or wl == "complex_fullloss":
+        model = (A.MediumIntensityDehazeModel() if wl == "config3" else A.HighIntensityDehazeModel()).to(device).train()
+        crit = DehazingLoss().to(device)
+        opt = Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+        sync = GradientSynchronizer(list(model.parameters()), world) if world > 1 else None
+        hazy, clear = synthetic_batch(bs, args.height, args.width, seed=42 + rank)
+        hazy, clear = hazy.to(device), clear.to(device)
+
+        def step():
+            opt.zero_grad()
+            loss, _ = crit(model(hazy), clear)
+            loss.backward()
+            if sync is not None:
+                sync.all_reduce()
+            opt.step()
+            return loss
+        desc = ("CORUN-Medium" if wl == "config3" else "CORUN-Complex") + \
+            " train fwd + DehazingLoss (L1 + 0.1 VGG16 content + 0.1 LPIPS, random-init extractors) + bwd + Adam"
+    else:                    # config4: the joint step (classifier + SoftRouter over 3 branches + JointLoss + Adam)
+        import yaml
+        cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "config.yaml")))
+        cfg["device"] = str(device)
+        cfg["classifier"]["pretrained"] = False
+        for k in ("classifier", "dehazing"):
+            cfg[k]["checkpoint_dir"] = "/nonexistent"
+        system = T.build_joint_system(cfg, world)
+        system["classifier"].train()
+        system["router"].train()
+        hazy, clear = synthetic_batch(bs, args.height, args.width, seed=42 + rank)
+        batch = {"hazy": hazy.to(device), "clear": clear.to(device),
+                 "intensity": (torch.arange(bs) % 3).to(device)}
+
+        def step():
+            return T.joint_train_step(system, batch)["loss"]
+        desc = "joint step: ResNet18 HDEN (train) + SoftRouter(Light, Medium, Complex) + JointLoss + duplicate-param Adam"
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"images/sec {wl}", "value": world * bs * args.steps / dt, "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "per_gpu_batch": bs, "global_batch": world * bs, "height": args.height,
+                       "width": args.width, "parallelism": f"dp{world}"},
+            "last_value": float(last.detach()) if torch.is_tensor(last) else None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +190,9 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="complex",
+                    choices=["complex", "complex_fullloss", "config2", "config3", "config4"],
+                    help="complex = headline (BASELINE.json metric); config2/3/4 = the other BASELINE.json configs")
     ap.add_argument("--no-adam", action="store_true")
     args = ap.parse_args()
 
@@ -126,6 +222,8 @@ def main():
     from adam_dehaze_amd.parallel import GradientSynchronizer
 
     torch.manual_seed(42)   # identical replicas on every rank
+    if args.workload != "complex":
+        return other_workloads(args, rank, world, device)
     model = A.HighIntensityDehazeModel().to(device).train()
     opt = None if args.no_adam else Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
     sync = GradientSynchronizer(list(model.parameters()), world) if world > 1 else None

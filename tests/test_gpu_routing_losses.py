@@ -278,7 +278,7 @@ def test_perceptual_loss_lpips_alex_vs_oracle():
     val.mean().backward()
     assert rel_err(p.grad, pr.grad) < 5e-3
     with torch.no_grad():
-        assert float(pl(p, p).abs().max()) == 0.0
+        assert float(pl(p, p).abs().max()) < 1e-12    # identical inputs (fma contraction leaves ~1e-17)
 
 
 def test_dehazing_loss_full_vs_oracle():
