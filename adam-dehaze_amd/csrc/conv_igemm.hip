@@ -204,6 +204,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const adh_conv_desc 
             const int vy = vy0 + 2 * wave + tm;
             const int oy = vy * d.out_sy + d.out_oy;
             const bool yvalid = cvalid && vy < d.VH;
+            // residual values are fetched for the whole 16-row fragment first so the loads overlap
+            float resv[16];
+            if (res_n) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int vx = vx0 + i;
+                    const bool valid = yvalid && vx < d.VW;
+                    const size_t pix = valid ? (size_t)oy * d.OW + (vx * d.out_sx + d.out_ox) : 0;
+                    resv[r] = res_n[valid ? pix * d.res_cstride + co : 0];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const adh_conv_desc 
                     ssum[tn] += v;
                     ssq[tn] += v * v;
                     const size_t pix = (size_t)oy * d.OW + (vx * d.out_sx + d.out_ox);
-                    if (res_n) v += res_n[pix * d.res_cstride + co];
+                    if (res_n) v += resv[r];
                     if (d.act == ADH_ACT_RELU) v = fmaxf(v, 0.f);
                     out_n[pix * d.out_cstride + co] = v;
                 }

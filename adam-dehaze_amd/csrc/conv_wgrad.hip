@@ -59,28 +59,53 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc 
             const int ix0 = vx0 * d.in_sx + g.dmin_x;
             const float* in_n = d.in + (size_t)n * d.IH * d.IW * d.in_cstride;
             const float* g_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
-#pragma unroll 4
-            for (int item = lt; item < xitems; item += 256) {
-                const int pix = item / XQ, cq = item - pix * XQ;
-                const int hy = pix / g.halo_w, hx = pix - hy * g.halo_w;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                const int ci = ci0 + cq * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW && ci < d.Cin)
-                    v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)iy * d.IW + ix) * d.in_cstride + ci);
-                *reinterpret_cast<f32x4*>(xs + pix * XP + cq * 4) = v;
-            }
-#pragma unroll 4
-            for (int item = lt; item < gitems; item += 256) {
-                const int pix = item / (BN / 4), cq = item - pix * (BN / 4);
-                const int vy = vy0 + (pix >> 5), vx = vx0 + (pix & 31);
-                const int co = co0 + cq * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (vy < d.VH && vx < d.VW && co < d.Cout) {
-                    const size_t opix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
-                    v = *reinterpret_cast<const f32x4*>(g_n + opix * d.out_cstride + co);
+            // loads are issued unconditionally (out-of-range lanes read the tensor base and are zeroed afterwards)
+            // in batches of 8 per thread so that 8 x 16 B per lane are in flight before the first LDS write
+            for (int base = lt; base < xitems; base += 256 * 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * 256;
+                    const int pix = item / XQ, cq = item - pix * XQ;
+                    const int hy = pix / g.halo_w, hx = pix - hy * g.halo_w;
+                    const int iy = iy0 + hy, ix = ix0 + hx;
+                    const int ci = ci0 + cq * 4;
+                    const bool ok = item < xitems && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW && ci < d.Cin;
+                    const float* src = ok ? in_n + ((size_t)iy * d.IW + ix) * d.in_cstride + ci : in_n;
+                    v[u] = *reinterpret_cast<const f32x4*>(src);
+                    if (!ok) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                *reinterpret_cast<f32x4*>(gs + pix * BN + cq * 4) = v;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * 256;
+                    if (item < xitems) {
+                        const int pix = item / XQ, cq = item - pix * XQ;
+                        *reinterpret_cast<f32x4*>(xs + pix * XP + cq * 4) = v[u];
+                    }
+                }
+            }
+            for (int base = lt; base < gitems; base += 256 * 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * 256;
+                    const int pix = item / (BN / 4), cq = item - pix * (BN / 4);
+                    const int vy = vy0 + (pix >> 5), vx = vx0 + (pix & 31);
+                    const int co = co0 + cq * 4;
+                    const bool ok = item < gitems && vy < d.VH && vx < d.VW && co < d.Cout;
+                    const size_t opix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
+                    const float* src = ok ? g_n + opix * d.out_cstride + co : g_n;
+                    v[u] = *reinterpret_cast<const f32x4*>(src);
+                    if (!ok) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * 256;
+                    if (item < gitems) {
+                        const int pix = item / (BN / 4), cq = item - pix * (BN / 4);
+                        *reinterpret_cast<f32x4*>(gs + pix * BN + cq * 4) = v[u];
+                    }
+                }
             }
         };
         if ((int)blockIdx.y < ntiles) stage(blockIdx.y, smem, smem + (size_t)g.npx * XP + 32);
