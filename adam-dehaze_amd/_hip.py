@@ -53,6 +53,9 @@ _SIGNATURES = {
     "adh_conv_num_blocks": [PD],
     "adh_pack_weights": [vp, vp, PL, vp],
     "adh_conv_forward": [vp, PD],
+    "adh_conv_wino_supported": [PD],
+    "adh_conv_wino_forward": [vp, PD],
+    "adh_pack_weights_wino": [vp, vp, PL, vp],
     "adh_conv_wgrad": [vp, PD, vp, i32],
     "adh_wgrad_reduce": [vp, vp, i32, i32, i32, PL, vp, i32],
     "adh_wgrad_reduce_packed": [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32],
@@ -116,7 +119,7 @@ _SIGNATURES = {
 }
 
 # functions that return a count / size rather than a status code
-_VALUE_FUNCS = {"adh_version", "adh_conv_lds_bytes", "adh_conv_num_blocks", "adh_bn_bwd_num_blocks",
+_VALUE_FUNCS = {"adh_version", "adh_conv_wino_supported", "adh_conv_lds_bytes", "adh_conv_num_blocks", "adh_bn_bwd_num_blocks",
                 "adh_cbam_pool_num_blocks", "adh_cbam_bwd_b_num_blocks", "adh_head_blend_bwd_num_blocks",
                 "adh_reduce_num_blocks", "adh_lpips_layer_num_blocks"}
 
@@ -164,23 +167,24 @@ class KernelTimer:
 
     def __init__(self, names):
         self.names = set(names)
-        self.records = []   # (name, start_event, end_event, work)
+        self.records = []   # (name, start_event, end_event, algorithmic work, executed work)
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, e0, e1, work in self.records:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+        for name, e0, e1, work, work_exec in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += work
-        return {k: {"launches": v[0], "seconds": v[1], "work": v[2]} for k, v in agg.items()}
+            a[3] += work_exec
+        return {k: {"launches": v[0], "seconds": v[1], "work": v[2], "work_exec": v[3]} for k, v in agg.items()}
 
 
 TIMER: Optional[KernelTimer] = None
 
 
-def call(name: str, *args, work: float = 0.0):
+def call(name: str, *args, work: float = 0.0, work_exec: Optional[float] = None):
     """Invoke a status-returning entry point on the current stream; raise on failure."""
     timer = TIMER
     if timer is not None and name in timer.names:
@@ -189,7 +193,7 @@ def call(name: str, *args, work: float = 0.0):
         e0.record()
         rc = getattr(load(), name)(stream_ptr(), *args)
         e1.record()
-        timer.records.append((name, e0, e1, work))
+        timer.records.append((name, e0, e1, work, work if work_exec is None else work_exec))
     else:
         rc = getattr(load(), name)(stream_ptr(), *args)
     if rc != 0:

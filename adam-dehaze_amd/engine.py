@@ -10,6 +10,7 @@ Reference semantics cited per op (paths under /root/reference).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -19,6 +20,8 @@ from ._hip import ConvDesc, WLayout
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+# Winograd F(2x2,3x3) for eligible 3x3 stride-1 convolutions and their data gradients (ADH_WINOGRAD=0 disables)
+USE_WINOGRAD = os.environ.get("ADH_WINOGRAD", "1") != "0"
 
 
 def _round_up(a: int, b: int) -> int:
@@ -249,7 +252,25 @@ class Engine:
                 VH, VW = dst_t.shape[1], dst_t.shape[2]
             d = self._conv_desc(src, Kp, dst_t, dstC, NcP, VH, VW, gm["KH"], gm["KW"], gm["in_s"], gm["out_s"],
                                 gm["out_o"], gm["dy0"], gm["dx0"], gm["dstep"])
-            wp = self._pack(w, L)   # keep alive until the launch below is enqueued
+            wino = False
+            if USE_WINOGRAD and gm["KH"] == 3 and gm["KW"] == 3 and gm["in_s"] == 1 and gm["out_s"] == 1 and Kp % 16 == 0 \
+                    and (gm["dy0"], gm["dx0"], gm["dstep"]) in ((-1, -1, 1), (1, 1, -1)):
+                Lw = L
+                if gm["dstep"] == -1:   # data gradient: the same correlation with the filter flipped in both axes
+                    Lw = WLayout(L.K, L.Nc, 3, 3, L.tap_off0 + 2 * L.tap_off_sy + 2 * L.tap_off_sx, -L.tap_off_sy,
+                                 -L.tap_off_sx, L.stride_k, L.stride_n)
+                    d.dy0 = d.dx0 = -1
+                    d.dstep_y = d.dstep_x = 1
+                wino = bool(H.value("adh_conv_wino_supported", C.byref(d)))
+                if wino:
+                    KQ = Kp // 4
+                    wp = self._f(16 * KQ * NcP * 4)
+                    H.call("adh_pack_weights_wino", w.data_ptr(), C.byref(Lw), wp.data_ptr())
+                else:
+                    d.dy0 = d.dx0 = gm["dy0"]
+                    d.dstep_y = d.dstep_x = gm["dstep"]
+            if not wino:
+                wp = self._pack(w, L)   # keep alive until the launch below is enqueued
             d.wp = wp.data_ptr()
             d.scale = H.ptr(scale)
             d.shift = H.ptr(shift)
@@ -258,7 +279,7 @@ class Engine:
                 d.res_cstride = residual.stride(2)
             d.act = act
             nb = H.value("adh_conv_num_blocks", C.byref(d))
-            descs.append((d, nb, wp))
+            descs.append((d, nb, wp, wino))
             total_blocks += nb
         stats = None
         if want_stats:
@@ -267,11 +288,15 @@ class Engine:
         row = 0
         row_i = 0
         flops_kn = [L.K * L.Nc for L, _ in plans]
-        for d, nb, _wp in descs:
+        for d, nb, _wp, wino in descs:
             if stats is not None:
                 d.stats = stats.data_ptr() + row * 2 * d.NcP * 4
-            # algorithmic FLOPs of this launch: 2 * virtual pixels * taps * real K * real Nc
-            H.call("adh_conv_forward", C.byref(d), work=2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i])
+            # algorithmic FLOPs of this launch: 2 * virtual pixels * taps * real K * real Nc (Winograd executes 4/9)
+            work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
+            if wino:
+                H.call("adh_conv_wino_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
+            else:
+                H.call("adh_conv_forward", C.byref(d), work=work)
             row += nb
             row_i += 1
         return stats, total_blocks

@@ -91,6 +91,12 @@ int adh_pack_weights(void* stream, const float* src, const adh_wlayout* L, float
 /* ---- convolution (base_model.py:11-13 Conv2d, medium_intensity.py:53,63 ConvTranspose2d) ---- */
 /* out = act(scale*gather_conv(in, wp) + shift + residual); optional BN statistics partials. */
 int adh_conv_forward(void* stream, const adh_conv_desc* d);
+/* Winograd F(2x2,3x3) path for 3x3 stride-1 pad-1 convolutions (and their data gradients): same descriptor
+ * and fused epilogue, d->wp packed by adh_pack_weights_wino (U = G g G^T per (k, n), [16][K/4][NcP][4]).
+ * adh_conv_wino_supported returns 1 when `d` is eligible (KH=KW=3, unit strides, dy0=dx0=-1, Cin % 16 == 0). */
+int adh_conv_wino_supported(const adh_conv_desc* d);
+int adh_conv_wino_forward(void* stream, const adh_conv_desc* d);
+int adh_pack_weights_wino(void* stream, const float* src, const adh_wlayout* L, float* wp);
 /* weight gradient of the gather form: slab[s][tap][KP][NcP] partial sums over `nsplit` pixel
  * ranges (KP = Cin rounded up to 32); d->out is the gradient wrt the conv output. */
 int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab, int nsplit);
