@@ -25,6 +25,22 @@
 #define WN_RAW_PX (10 * WN_RAW_W)               // raw halo pixels of one 8x32 region
 #define WN_RAW_IT 6                             // ceil(340 * 4 / 256) float4 per producer thread
 
+// Weight prefetch outside hipcc's waitcnt bookkeeping (cdna_hip_programming.md 5.7): hipcc waits for a plain
+// prefetch at the first MFMA of the SAME chunk (a conservative vmcnt on the loop-carried register set), exposing the
+// L2 latency every chunk.  The asm load is invisible to that pass; wait_b() is the hand-placed wait, naming every
+// destination so no consumer is scheduled above it.  The consumer waves issue no other vector-memory operation
+// inside the chunk loop, so vmcnt(0) there waits exactly for the set issued one chunk earlier.
+__device__ __forceinline__ void gload_b128(f32x4& dst, const f32x4* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void wait_b(f32x4 (&b)[4][2]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]),
+                   "+v"(b[3][1])
+                 :
+                 : "memory");
+}
+
 struct WinoGeom {
     int tiles_x, tiles_y;        // 32-col x 8-row regions
     int nchunks;
@@ -76,15 +92,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const adh_conv_desc d
             const float* base = in_n + c * WN_KC;
 #pragma unroll
             for (int it = 0; it < WN_RAW_IT; ++it) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(goff[it] >= 0 ? base + goff[it] : in_n);   // unconditional
-                rr[it] = goff[it] >= 0 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                // unconditional load (out-of-image lanes read the tensor base and are zeroed when stored), so the six
+                // loads stay in flight across the next barrier instead of being waited for here
+                rr[it] = *reinterpret_cast<const f32x4*>(goff[it] >= 0 ? base + goff[it] : in_n);
             }
         };
         auto store_raw = [&]() {
 #pragma unroll
             for (int it = 0; it < WN_RAW_IT; ++it) {
                 const int item = pt + it * 256;
-                if (item < WN_RAW_PX * 4) raw[(item & 3) * WN_RAW_PX + (item >> 2)] = rr[it];
+                if (item < WN_RAW_PX * 4)
+                    raw[(item & 3) * WN_RAW_PX + (item >> 2)] = goff[it] >= 0 ? rr[it] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
         const f32x4* patch = raw + cq * WN_RAW_PX + (2 * trow) * WN_RAW_W + 2 * tcol;
@@ -134,41 +152,64 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const adh_conv_desc d
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[fl][mb][r] = 0.f;
         const f32x4* U4 = reinterpret_cast<const f32x4*>(d.wp);
-        f32x4 bcur[4][2], bnxt[4][2];
+        f32x4 bA[4][2], bB[4][2];   // two weight register sets, ping-ponged over an unrolled-by-two chunk loop
         auto fetch_b = [&](int c, f32x4 (&b)[4][2]) {
 #pragma unroll
             for (int fl = 0; fl < 4; ++fl)
 #pragma unroll
                 for (int gg = 0; gg < 2; ++gg)
-                    b[fl][gg] = U4[(size_t)((wave * 4 + fl) * g.KQtot + c * (WN_KC / 4) + 2 * gg + h) * d.NcP + co0 + l31];
+                    gload_b128(b[fl][gg],
+                               U4 + (size_t)((wave * 4 + fl) * g.KQtot + c * (WN_KC / 4) + 2 * gg + h) * d.NcP + co0 + l31);
         };
-        fetch_b(0, bcur);
+        auto contract = [&](int c, const f32x4 (&bw)[4][2]) {
+            const f32x4* Vb = lds + (c & 1) * WN_VBUF + h * WN_TILES + l31;
+            // 4 double steps: two frequencies x one channel group each, i.e. 16 MFMAs on FOUR accumulators issued
+            // round-robin (dependent MFMAs are 4 issue slots apart); the LDS operands of double step s+1 are read
+            // before the MFMAs of double step s issue
+            auto rd = [&](int ds, f32x4 (&a)[4]) {
+                const int p = ds >> 1, gg = ds & 1;
+                const f32x4* v0 = Vb + ((wave * 4 + 2 * p) * (WN_KC / 4) + 2 * gg) * WN_TILES;
+                const f32x4* v1 = v0 + (WN_KC / 4) * WN_TILES;
+                a[0] = v0[0];
+                a[1] = v0[32];
+                a[2] = v1[0];
+                a[3] = v1[32];
+            };
+            f32x4 ac[4], an[4];
+            rd(0, ac);
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const int p = ds >> 1, gg = ds & 1;
+                if (ds == 1) __syncthreads();   // m_c
+                if (ds < 3) rd(ds + 1, an);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 b0 = bw[2 * p][gg], b1 = bw[2 * p + 1][gg];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * p][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0][j], b0[j], acc[2 * p][0], 0, 0, 0);
+                    acc[2 * p][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[1][j], b0[j], acc[2 * p][1], 0, 0, 0);
+                    acc[2 * p + 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[2][j], b1[j], acc[2 * p + 1][0], 0, 0, 0);
+                    acc[2 * p + 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[3][j], b1[j], acc[2 * p + 1][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ac[i] = an[i];
+            }
+            __syncthreads();   // b_{c+1} (E1 after the last chunk)
+        };
+        fetch_b(0, bA);
         __syncthreads();       // P
         __syncthreads();       // b_0
-        for (int c = 0; c < g.nchunks; ++c) {
-            if (c + 1 < g.nchunks) fetch_b(c + 1, bnxt);
-            const f32x4* Vb = lds + (c & 1) * WN_VBUF;
-#pragma unroll
-            for (int fl = 0; fl < 4; ++fl) {
-                if (fl == 2) __syncthreads();   // m_c
-                const int f = wave * 4 + fl;
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    const f32x4* vp = Vb + (f * (WN_KC / 4) + 2 * gg + h) * WN_TILES + l31;
-                    const f32x4 a0 = vp[0], a1 = vp[32];
-                    const f32x4 b = bcur[fl][gg];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[fl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[j], acc[fl][0], 0, 0, 0);
-                        acc[fl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[j], acc[fl][1], 0, 0, 0);
-                    }
-                }
+        for (int c = 0; c < g.nchunks; c += 2) {
+            wait_b(bA);                                   // issued one chunk ago: already landed
+            if (c + 1 < g.nchunks) fetch_b(c + 1, bB);   // next chunk's weights stay in flight during this contraction
+            __builtin_amdgcn_sched_barrier(0);
+            contract(c, bA);
+            if (c + 1 < g.nchunks) {
+                wait_b(bB);
+                if (c + 2 < g.nchunks) fetch_b(c + 2, bA);
+                __builtin_amdgcn_sched_barrier(0);
+                contract(c + 1, bB);
             }
-#pragma unroll
-            for (int fl = 0; fl < 4; ++fl)
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg) bcur[fl][gg] = bnxt[fl][gg];
-            __syncthreads();   // b_{c+1} (E1 after the last chunk)
         }
         float* M = reinterpret_cast<float*>(lds);   // [16][64][32]
 #pragma unroll
