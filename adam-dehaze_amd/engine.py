@@ -76,6 +76,22 @@ class BNState:
         self.num_batches_tracked = num_batches_tracked
 
 
+def _rows_nsplit(groups: int, ntiles: int, cus: int = 256) -> int:
+    """Pixel splits for the row-split weight-gradient kernel: one workgroup is resident per CU, so pick the
+    smallest nsplit (up to 4 rounds) whose groups*nsplit workgroups fill whole rounds of `cus` best."""
+    best, best_eff = 1, 0.0
+    for ns in range(1, max(1, min(ntiles, 4 * cus // max(1, groups) + 1)) + 1):
+        total = groups * ns
+        rounds = -(-total // cus)
+        eff = total / (rounds * cus)
+        # tiles per split must also divide evenly enough
+        per = -(-ntiles // ns)
+        eff *= ntiles / (per * ns)
+        if eff > best_eff + 1e-3:
+            best, best_eff = ns, eff
+    return best
+
+
 class Engine:
     def __init__(self, device: torch.device, record: bool):
         self.device = device
@@ -324,16 +340,19 @@ class Engine:
             groups = (KP // 32) * max(1, NcP // 96) * zgroups
             # one 512-thread workgroup per CU is resident: aim at ~4 rounds of 256 workgroups
             nsplit = max(1, min(ntiles_est, max(1, 1024 // groups), 512))
+            rows_groups = H.value("adh_conv_wgrad_groups", C.byref(d))
+            if rows_groups:
+                nsplit = _rows_nsplit(rows_groups, ntiles_est)
             T = gm["KH"] * gm["KW"]
-            slab_elems = nsplit * T * KP * NcP
+            nslabs = H.value("adh_conv_wgrad_slabs", C.byref(d), nsplit)
             # cap the slab at 1 GiB
-            while slab_elems * 4 > (1 << 30) and nsplit > 1:
+            while nslabs * T * KP * NcP * 4 > (1 << 30) and nsplit > 1:
                 nsplit //= 2
-                slab_elems = nsplit * T * KP * NcP
-            slab = self._f(slab_elems)
+                nslabs = H.value("adh_conv_wgrad_slabs", C.byref(d), nsplit)
+            slab = self._f(nslabs * T * KP * NcP)
             H.call("adh_conv_wgrad", C.byref(d), slab.data_ptr(), nsplit,
                    work=2.0 * d.N * d.VH * d.VW * T * L.K * L.Nc)
-            H.call("adh_wgrad_reduce", slab.data_ptr(), nsplit, KP, NcP, C.byref(L), dw.data_ptr(), 0)
+            H.call("adh_wgrad_reduce", slab.data_ptr(), nslabs, KP, NcP, C.byref(L), dw.data_ptr(), 0)
         return dw
 
     def _wgrad_packed_stem(self, gm, x: Act, g_y: torch.Tensor, gC: int, w: torch.Tensor, dw: torch.Tensor):

@@ -100,6 +100,12 @@ int adh_pack_weights_wino(void* stream, const float* src, const adh_wlayout* L, 
 /* weight gradient of the gather form: slab[s][tap][KP][NcP] partial sums over `nsplit` pixel
  * ranges (KP = Cin rounded up to 32); d->out is the gradient wrt the conv output. */
 int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab, int nsplit);
+/* number of slabs adh_conv_wgrad writes for (d, nsplit): nsplit, or 4*nsplit on the 3x3 unit-stride path whose
+ * four waves each keep their own partial sums; size `slab` and call adh_wgrad_reduce with this count. */
+int adh_conv_wgrad_slabs(const adh_conv_desc* d, int nsplit);
+/* 3x3 unit-stride path only (0 otherwise): workgroups per pixel split.  One workgroup is resident per CU, so
+ * callers pick nsplit with groups*nsplit close to a multiple of the CU count. */
+int adh_conv_wgrad_groups(const adh_conv_desc* d);
 /* dst(layout L) (+)= sum_s slab[s]; deterministic order. accumulate != 0 adds to dst. */
 int adh_wgrad_reduce(void* stream, const float* slab, int nsplit, int KP, int NcP,
                      const adh_wlayout* L, float* dst, int accumulate);
