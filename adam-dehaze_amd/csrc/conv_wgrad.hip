@@ -195,24 +195,36 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// 3x3 / unit-stride fast path ("row split").  Measured on gfx950: every VALU instruction issued on a SIMD takes
-// ~5-8 cycles away from its fp32 MFMA pipe (tools/micro/mfma_mix.hip), so this kernel keeps the vector ALU
-// idle in steady state:
+// "Row split" fast path.  Measured on gfx950: every VALU instruction issued on a SIMD takes ~5-8 cycles away
+// from its fp32 MFMA pipe (tools/micro/mfma_mix.hip), so this kernel keeps the vector ALU idle in steady state:
 //   * 4 waves (one per SIMD, the whole 512-register file each).  A workgroup owns 32 input channels x 32*TN
-//     output channels x 9 taps and sweeps a contiguous range of pixel tiles (4 rows x 32 columns); wave w
-//     contracts pixel row w of every tile into ALL 9*TN accumulator tiles, i.e. the pixel (k) dimension is
-//     split over the waves and every wave runs the same instruction stream;
-//   * the input halo [6][40 px][32 ch] and the G tile [TN][128 px][32 ch] arrive by LDS-DMA
+//     output channels x KH*KW taps and sweeps a contiguous range of pixel tiles (4 rows x 32 columns); wave w
+//     contracts pixel row w of every tile into ALL KH*KW*TN accumulator tiles, i.e. the pixel (k) dimension
+//     is split over the waves and every wave runs the same instruction stream;
+//   * the input halo [4+KH-1][40 px][32 ch] and the G tile [TN][128 px][32 ch] arrive by LDS-DMA
 //     (buffer_load_dwordx4 ... lds: per-lane offset constant for the whole kernel, per-instruction scalar
 //     offset), double buffered, one barrier per tile, no staging registers and no ds_write;
 //   * every MFMA operand is a ds_read_b32 whose tap / step / n-tile offset is an instruction immediate.
 // Out-of-image halo rows are zero-filled instead of loaded; out-of-image halo columns are lane-masked and
 // zero-filled (buffer range checking does not cover the scalar offset, so nothing is read out of bounds).
 // Wave w of pixel split s writes slab[4*s + w].
-#define WR_HP 40   // halo row pitch in pixels (5 DMA pieces of 8 pixels; 34 used)
+//
+// Shapes: taps step through the input in units of the per-pixel input stride (|dstep| == in_s), so the halo
+// is a dense patch of the in_s-subsampled input.  That covers Conv2d 3x3 s1 (3x3 taps), every output-parity
+// class of ConvTranspose2d k4 s2 (2x2 taps walked backwards, G strided by 2) and Conv2d k4 s2, which the host
+// splits into its four kernel-parity classes (2x2 taps with step 2 on the stride-2 input grid).
+#define WR_HP 40   // halo row pitch in pixels (5 DMA pieces of 8 pixels; 32+KW-1 used)
 #define WR_TH 4
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+struct WrArgs {
+    int ymin, xmin;            // input pixel of halo (0,0) for virtual pixel (0,0)
+    int xps;                   // input pixels per halo pixel (in_s)
+    int Ttot;                  // taps of the slab (KH*KW of the full kernel)
+    int tap0, tap_sy, tap_sx;  // slab tap index of this launch's tap (ty, tx)
+    int ntiles, nsplit, ngroups, nco_groups, tiles_x, tiles_y;
+};
 
 // Accumulator tile IDX of a wave: the first 16 tiles live in the 256 AGPRs, the rest in VGPRs.  hipcc would
 // otherwise keep >256 accumulator registers in AGPRs and copy every tile to VGPRs and back around each MFMA
@@ -222,20 +234,25 @@ __device__ __forceinline__ void wr_mfma(f32x16& c, float a, float b) {
     if constexpr (IDX < 16) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-template <int TN, int I>
-__device__ __forceinline__ void wr_mfma_all(f32x16 (&acc)[9 * TN], const float (&a)[9], const float (&b)[TN]) {
-    if constexpr (I < 9 * TN) {
+template <int T, int TN, int I>
+__device__ __forceinline__ void wr_mfma_all(f32x16 (&acc)[T * TN], const float (&a)[T], const float (&b)[TN]) {
+    if constexpr (I < T * TN) {
         wr_mfma<I>(acc[I], a[I / TN], b[I % TN]);
-        wr_mfma_all<TN, I + 1>(acc, a, b);
+        wr_mfma_all<T, TN, I + 1>(acc, a, b);
     }
 }
 
-template <int TN>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_desc d, float* slab, int ntiles,
-                                                                 int nsplit, int ngroups, int nco_groups, int tiles_x,
-                                                                 int tiles_y) {
+// REV: taps walk backwards through the halo (dstep < 0): tap (ty, tx) reads halo offset (KH-1-ty, KW-1-tx)
+template <int KH, int KW, bool REV, int TN>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_desc d, const WrArgs g, float* slab) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int XF = (WR_TH + 2) * WR_HP * 32;   // floats of the halo image
+    constexpr int T = KH * KW;
+    constexpr int HR = WR_TH + KH - 1;             // halo rows
+    constexpr int NC = 32 + KW - 1;                // halo columns in use
+    constexpr int NP = HR * 5;                     // DMA pieces of the halo
+    constexpr int PU = (NP + 3) / 4;               // pieces per wave (at most)
+    static_assert(PU <= 8, "halo piece tables hold 8 entries");
+    constexpr int XF = HR * WR_HP * 32;            // floats of the halo image
     constexpr int GF = TN * WR_TH * 32 * 32;       // floats of the G image
     constexpr int BUF = XF + GF;
 
@@ -250,78 +267,85 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int q = bid >> 3;
-    const int grp = q % ngroups;
-    const int split = (q / ngroups) * 8 + xcd;
-    if (split >= nsplit) return;
-    const int ci_tile = grp / nco_groups;
-    const int co_grp = grp - ci_tile * nco_groups;
+    const int grp = q % g.ngroups;
+    const int split = (q / g.ngroups) * 8 + xcd;
+    if (split >= g.nsplit) return;
+    const int ci_tile = grp / g.nco_groups;
+    const int co_grp = grp - ci_tile * g.nco_groups;
     const int ci0 = ci_tile * 32;
     const int co0 = co_grp * 32 * TN;
 
     // contiguous tile range of this split
-    const int per = ntiles / nsplit, rem = ntiles - per * nsplit;
+    const int per = g.ntiles / g.nsplit, rem = g.ntiles - per * g.nsplit;
     const int t_begin = split * per + adh_min_i(split, rem);
     const int t_end = t_begin + per + (split < rem ? 1 : 0);
 
-    // Buffer descriptors.  The halo descriptor's base is the (virtual) pixel (dy0, dx0) of image 0, so every scalar
-    // offset below is non-negative; lanes / rows that would fall outside the tensor are never issued.
-    const int xcs = d.in_cstride * 4, gcs = d.out_cstride * 4;   // pixel pitches in bytes
-    const float* xbase = d.in + ((int64_t)d.dy0 * d.IW + d.dx0) * d.in_cstride + ci0;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(d.out + co0, 0, 0x7fffffff, 0x00020000);
+    // Buffer descriptors.  The halo descriptor's base is the (virtual) pixel (ymin, xmin) of the image, so every
+    // scalar offset below is non-negative; lanes / rows that would fall outside the tensor are never issued.
+    // Offsets are 32-bit and relative to the current image, whose base goes into the descriptor (rebuilt per
+    // tile: four scalar instructions), so only one image has to stay below 2 GiB.
+    const int xcs = d.in_cstride * 4 * g.xps, gcs = d.out_cstride * 4 * d.out_sx;   // halo / G pixel pitches in bytes
+    const int xrs = d.IW * d.in_cstride * 4 * g.xps, grs = d.OW * d.out_cstride * 4 * d.out_sy;   // row pitches
+    const float* xbase = d.in + ((int64_t)g.ymin * d.IW + g.xmin) * d.in_cstride + ci0;
+    const float* gbase = d.out + ((int64_t)d.out_oy * d.OW + d.out_ox) * d.out_cstride + co0;
+    const int64_t ximg = (int64_t)d.IH * d.IW * d.in_cstride, gimg = (int64_t)d.OH * d.OW * d.out_cstride;
     const int xv = (lane >> 3) * xcs + (lane & 7) * 16;    // per-lane byte offsets inside one 8-pixel piece
     const int gv = (lane >> 3) * gcs + (lane & 7) * 16;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // this wave's halo pieces: piece j = wave + 4u covers halo row j/5, pixels 8*(j%5) .. +7 (wave-uniform scalars)
-    int prow[8], pcb[8], poff[8], pdst[8];
+    int prow[8], pcb[8], poff[8], pdst[8];   // PU <= 8 (sized literally: a dependent bound breaks hipcc's host pass)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < PU; ++u) {
         const int j = wave + 4 * u;
         prow[u] = j / 5;
         pcb[u] = j - prow[u] * 5;
-        poff[u] = (prow[u] * d.IW + pcb[u] * 8) * xcs;
+        poff[u] = prow[u] * xrs + pcb[u] * 8 * xcs;
         pdst[u] = (prow[u] * WR_HP + pcb[u] * 8) * 32;
     }
-    const int npieces = wave < 2 ? 8 : 7;
-    const bool last16 = lane < 16;   // lanes of a right-most piece (pixels 32, 33)
+    const int npieces = (NP - wave + 3) / 4;
+    const bool tail_ok = (lane >> 3) < NC - 32;   // lanes of a right-most piece that hold used pixels
 
     // stage tile (n, ty, tx) into buffer `b`: this wave's share of the DMA pieces
     auto stage = [&](int n, int ty, int tx, int b) {
         float* xs = smem + b * BUF;
         float* gs = xs + XF;
-        const int iy0 = ty * WR_TH + d.dy0, ix0 = tx * 32 + d.dx0;
-        const int so = ((n * d.IH + ty * WR_TH) * d.IW + tx * 32) * xcs;
-        const bool interior = iy0 >= 0 && iy0 + WR_TH + 2 <= d.IH && ix0 >= 0 && ix0 + 34 <= d.IW;
+        const __amdgpu_buffer_rsrc_t xr =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase + n * ximg), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t gr =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gbase + n * gimg), 0, 0x7fffffff, 0x00020000);
+        // input pixel of halo (0,0) and of its last used row / column
+        const int iy0 = ty * WR_TH * g.xps + g.ymin, ix0 = tx * 32 * g.xps + g.xmin;
+        const int so = ty * WR_TH * xrs + tx * 32 * xcs;
+        const bool interior = iy0 >= 0 && iy0 + (HR - 1) * g.xps < d.IH && ix0 >= 0 && ix0 + (NC - 1) * g.xps < d.IW;
         if (interior) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < PU; ++u) {
                 if (u < npieces) {
                     float* dst = xs + pdst[u];
                     if (pcb[u] == 4) {
-                        if (last16) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, so + poff[u], 0, 0);
+                        if (tail_ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, so + poff[u], 0, 0);
                     } else {
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, so + poff[u], 0, 0);
                     }
                 }
             }
         } else {
-            const bool left = ix0 < 0, right = ix0 + 34 > d.IW;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < PU; ++u) {
                 if (u < npieces) {
                     float* dst = xs + pdst[u];
-                    const int iy = iy0 + prow[u];
-                    const bool row_ok = iy >= 0 && iy < d.IH;
+                    const int iy = iy0 + prow[u] * g.xps;
                     const int c = pcb[u] * 8 + (lane >> 3);
-                    const bool lane_ok = row_ok && c < 34 && !(left && c == 0) && !(right && c == 33);
+                    const int ix = ix0 + c * g.xps;
+                    const bool lane_ok = iy >= 0 && iy < d.IH && c < NC && ix >= 0 && ix < d.IW;
                     if (lane_ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, so + poff[u], 0, 0);
-                    if (!lane_ok && c < 34) *reinterpret_cast<f32x4*>(dst + lane * 4) = zero4;
+                    if (!lane_ok && c < NC) *reinterpret_cast<f32x4*>(dst + lane * 4) = zero4;
                 }
             }
         }
         // G: wave w stages pixel row w: TN x 4 pieces (always inside the tensor)
-        const int sg = ((n * d.OH + ty * WR_TH + wave) * d.OW + tx * 32) * gcs;
+        const int sg = (ty * WR_TH + wave) * grs + tx * 32 * gcs;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -331,16 +355,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
             }
     };
 
-    f32x16 acc[9 * TN];
+    f32x16 acc[T * TN];
 #pragma unroll
-    for (int t = 0; t < 9 * TN; ++t)
+    for (int t = 0; t < T * TN; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // tile coordinates advance incrementally (scalar)
-    int tx = t_begin % tiles_x;
-    int ty = (t_begin / tiles_x) % tiles_y;
-    int n = t_begin / (tiles_x * tiles_y);
+    int tx = t_begin % g.tiles_x;
+    int ty = (t_begin / g.tiles_x) % g.tiles_y;
+    int n = t_begin / (g.tiles_x * g.tiles_y);
     if (t_begin < t_end) stage(n, ty, tx, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -348,30 +372,33 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
     int cur = 0;
     for (int tile = t_begin; tile < t_end; ++tile) {
         int ntx = tx + 1, nty = ty, nn = n;
-        if (ntx == tiles_x) { ntx = 0; ++nty; }
-        if (nty == tiles_y) { nty = 0; ++nn; }
+        if (ntx == g.tiles_x) { ntx = 0; ++nty; }
+        if (nty == g.tiles_y) { nty = 0; ++nn; }
         if (tile + 1 < t_end) stage(nn, nty, ntx, cur ^ 1);
 
         const float* xl = smem + cur * BUF + (wave * WR_HP + h) * 32 + l31;
         const float* gl = smem + cur * BUF + XF + (wave * 32 + h) * 32 + l31;
-        float a0[9], b0[TN], a1[9], b1[TN];
-        auto ld = [&](const float* xp, const float* gp, float (&av)[9], float (&bv)[TN]) {
+        float a0[T], b0[TN], a1[T], b1[TN];
+        auto ld = [&](const float* xp, const float* gp, float (&av)[T], float (&bv)[TN]) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) av[t] = xp[((t / 3) * WR_HP + (t % 3)) * 32];
+            for (int t = 0; t < T; ++t) {
+                const int oy = REV ? KH - 1 - t / KW : t / KW, ox = REV ? KW - 1 - t % KW : t % KW;
+                av[t] = xp[(oy * WR_HP + ox) * 32];
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) bv[j] = gp[j * 128 * 32];
         };
         // software pipeline over the 16 pixel pairs of this wave's row: operands of pair s+1 are in flight while
-        // the 9*TN MFMAs of pair s issue (two register sets, pointers bumped once per two pairs)
+        // the T*TN MFMAs of pair s issue (two register sets, pointers bumped once per two pairs)
         ld(xl, gl, a0, b0);
 #pragma unroll 1
         for (int st = 0; st < 16; st += 2) {
             ld(xl + 64, gl + 64, a1, b1);
-            wr_mfma_all<TN, 0>(acc, a0, b0);
+            wr_mfma_all<T, TN, 0>(acc, a0, b0);
             xl += 128;
             gl += 128;
             if (st + 2 < 16) ld(xl, gl, a0, b0);
-            wr_mfma_all<TN, 0>(acc, a1, b1);
+            wr_mfma_all<T, TN, 0>(acc, a1, b1);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -381,18 +408,20 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
 
     // partial result -> slab[4*split + wave][tap][KP][NcP]
     const int KP = d.Cin;
-    float* sbase = slab + ((size_t)(split * 4 + wave) * 9) * KP * d.NcP;
+    float* sbase = slab + ((size_t)(split * 4 + wave) * g.Ttot) * KP * d.NcP;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < T; ++t) {
+        const int tap = g.tap0 + (t / KW) * g.tap_sy + (t % KW) * g.tap_sx;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            float* base = sbase + ((size_t)t * KP + ci0) * d.NcP + co0 + 32 * j + l31;
+            float* base = sbase + ((size_t)tap * KP + ci0) * d.NcP + co0 + 32 * j + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
                 base[(size_t)i * d.NcP] = acc[t * TN + j][r];
             }
         }
+    }
 }
 
 __host__ static int wgrad_geometry(const adh_conv_desc* d, ConvGeom* g, int TN, int xp) {
@@ -442,55 +471,111 @@ static int wgrad_pick_tn(int NcP, int T) {
     return 1;
 }
 
-// row-split fast path eligibility and its n-tile width
-static int wgrad_rows_tn(const adh_conv_desc* d) {
-    if (d->KH != 3 || d->KW != 3 || d->dstep_y != 1 || d->dstep_x != 1) return 0;
-    if (d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy != 0 || d->out_ox != 0) return 0;
-    if (d->VH != d->OH || d->VW != d->OW || d->VW % 32 != 0 || d->VH % WR_TH != 0) return 0;
-    if (d->dy0 > 0 || d->dy0 < -2 || d->dx0 > 0 || d->dx0 < -2) return 0;
+// Row-split fast path: eligibility and launch plan.  Returns the number of sub-launches (0 = not eligible).
+struct WrPlan {
+    int KH, KW, rev, TN;
+    WrArgs a;
+};
+
+static int wgrad_rows_plan(const adh_conv_desc* d, int nsplit, WrPlan plan[4]) {
+    if (d->VW % 32 != 0 || d->VH % WR_TH != 0) return 0;
     if (d->Cin % 32 != 0 || d->Cout % 32 != 0 || d->NcP != d->Cout) return 0;
     if (d->in_cstride % 4 != 0 || d->out_cstride % 4 != 0) return 0;
-    // 32-bit byte offsets inside the buffer descriptors
-    if ((int64_t)d->N * d->IH * d->IW * d->in_cstride * 4 >= (int64_t)1 << 31) return 0;
-    if ((int64_t)d->N * d->OH * d->OW * d->out_cstride * 4 >= (int64_t)1 << 31) return 0;
+    if (d->in_sy != d->in_sx || d->dstep_y != d->dstep_x || d->out_sy != d->out_sx) return 0;
+    if ((d->VH - 1) * d->out_sy + d->out_oy >= d->OH || (d->VW - 1) * d->out_sx + d->out_ox >= d->OW) return 0;
+    // 32-bit byte offsets inside one image (the descriptors are per image)
+    if ((int64_t)(d->IH + 8) * d->IW * d->in_cstride * 4 >= (int64_t)1 << 31) return 0;
+    if ((int64_t)d->OH * d->OW * d->out_cstride * 4 >= (int64_t)1 << 31) return 0;
     const int t = d->Cout / 32;
-    return t % 3 == 0 ? 3 : (t % 2 == 0 ? 2 : 1);
+    const int TN = t % 3 == 0 ? 3 : (t % 2 == 0 ? 2 : 1);
+    WrArgs base;
+    base.tiles_x = d->VW / 32;
+    base.tiles_y = d->VH / WR_TH;
+    base.ntiles = base.tiles_x * base.tiles_y * d->N;
+    base.nsplit = nsplit;
+    base.nco_groups = d->Cout / (32 * TN);
+    base.ngroups = (d->Cin / 32) * base.nco_groups;
+    base.Ttot = d->KH * d->KW;
+    const int s = d->in_sy, ds = d->dstep_y;
+    if (((d->KH == 3 && d->KW == 3) || (d->KH == 2 && d->KW == 2)) && (ds == s || ds == -s) && (s == 1 || s == 2)) {
+        // dense patch of the s-subsampled input; reversed taps start (K-1) steps earlier
+        WrPlan& p = plan[0];
+        p.KH = d->KH; p.KW = d->KW; p.rev = ds < 0; p.TN = TN;
+        p.a = base;
+        p.a.xps = s;
+        p.a.ymin = d->dy0 + (ds < 0 ? (d->KH - 1) * ds : 0);
+        p.a.xmin = d->dx0 + (ds < 0 ? (d->KW - 1) * ds : 0);
+        p.a.tap0 = 0; p.a.tap_sy = d->KW; p.a.tap_sx = 1;
+        return 1;
+    }
+    if (d->KH == 4 && d->KW == 4 && s == 2 && ds == 1) {
+        // Conv2d k4 s2: kernel index ky = 2*ty + py reads input row 2*(vy + ty) + dy0 + py -- for each kernel parity
+        // (py, px) a 2x2-tap problem on the stride-2 input grid
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                WrPlan& p = plan[py * 2 + px];
+                p.KH = 2; p.KW = 2; p.rev = 0; p.TN = TN;
+                p.a = base;
+                p.a.xps = 2;
+                p.a.ymin = d->dy0 + py;
+                p.a.xmin = d->dx0 + px;
+                p.a.tap0 = py * 4 + px; p.a.tap_sy = 8; p.a.tap_sx = 2;
+            }
+        return 4;
+    }
+    return 0;
 }
 
-template <int TN>
-static int launch_wgrad_rows(hipStream_t s, const adh_conv_desc* d, float* slab, int nsplit) {
-    const int tiles_x = d->VW / 32, tiles_y = d->VH / WR_TH;
-    const int ntiles = tiles_x * tiles_y * d->N;
-    const int nco_groups = d->Cout / (32 * TN);
-    const int ngroups = (d->Cin / 32) * nco_groups;
-    const int lds = 2 * (((WR_TH + 2) * WR_HP + TN * WR_TH * 32) * 32 * 4);
-    const int nblocks = ((nsplit + 7) / 8) * ngroups * 8;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_kernel<TN>),
+template <int KH, int KW, bool REV, int TN>
+static int launch_wgrad_rows(hipStream_t s, const adh_conv_desc* d, const WrArgs& a, float* slab) {
+    const int lds = 2 * (((WR_TH + KH - 1) * WR_HP + TN * WR_TH * 32) * 32 * 4);
+    const int nblocks = ((a.nsplit + 7) / 8) * a.ngroups * 8;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_kernel<KH, KW, REV, TN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_wgrad_rows_kernel<TN>), dim3(nblocks), dim3(256), lds, s, *d, slab, ntiles, nsplit, ngroups,
-                       nco_groups, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<KH, KW, REV, TN>), dim3(nblocks), dim3(256), lds, s, *d, a, slab);
     return adh_check_launch();
+}
+
+static int dispatch_wgrad_rows(hipStream_t s, const adh_conv_desc* d, const WrPlan& p, float* slab) {
+#define WR_CASE(kh_, kw_, rev_, tn_) \
+    if (p.KH == kh_ && p.KW == kw_ && p.rev == rev_ && p.TN == tn_) \
+        return launch_wgrad_rows<kh_, kw_, rev_ != 0, tn_>(s, d, p.a, slab);
+    WR_CASE(3, 3, 0, 3) WR_CASE(3, 3, 0, 2) WR_CASE(3, 3, 0, 1)
+    WR_CASE(2, 2, 0, 3) WR_CASE(2, 2, 0, 2) WR_CASE(2, 2, 0, 1)
+    WR_CASE(2, 2, 1, 3) WR_CASE(2, 2, 1, 2) WR_CASE(2, 2, 1, 1)
+#undef WR_CASE
+    return ADH_E_UNSUPPORTED;
+}
+
+static bool wgrad_rows_instantiated(const WrPlan& p) {
+    return (p.KH == 3 && p.KW == 3 && !p.rev) || (p.KH == 2 && p.KW == 2);
 }
 
 extern "C" int adh_conv_wgrad_groups(const adh_conv_desc* d) {
     if (!d) return ADH_E_ARG;
-    const int tn = wgrad_rows_tn(d);
-    return tn ? (d->Cin / 32) * (d->Cout / (32 * tn)) : 0;
+    WrPlan plan[4];
+    const int n = wgrad_rows_plan(d, 1, plan);
+    return n && wgrad_rows_instantiated(plan[0]) ? plan[0].a.ngroups : 0;
 }
 
 extern "C" int adh_conv_wgrad_slabs(const adh_conv_desc* d, int nsplit) {
     if (!d || nsplit < 1) return ADH_E_ARG;
-    return wgrad_rows_tn(d) ? 4 * nsplit : nsplit;
+    return adh_conv_wgrad_groups(d) > 0 ? 4 * nsplit : nsplit;
 }
 
 extern "C" int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab, int nsplit) {
     if (!d || !slab || nsplit < 1 || !d->in || !d->out) return ADH_E_ARG;
     if (d->NcP % 32 != 0 || d->NcP < d->Cout) return ADH_E_ARG;
-    switch (wgrad_rows_tn(d)) {
-        case 3: return launch_wgrad_rows<3>((hipStream_t)stream, d, slab, nsplit);
-        case 2: return launch_wgrad_rows<2>((hipStream_t)stream, d, slab, nsplit);
-        case 1: return launch_wgrad_rows<1>((hipStream_t)stream, d, slab, nsplit);
-        default: break;
+    {
+        WrPlan plan[4];
+        const int np = wgrad_rows_plan(d, nsplit, plan);
+        if (np && wgrad_rows_instantiated(plan[0])) {
+            for (int i = 0; i < np; ++i) {
+                const int rc = dispatch_wgrad_rows((hipStream_t)stream, d, plan[i], slab);
+                if (rc) return rc;
+            }
+            return ADH_OK;
+        }
     }
     const int Ttot = d->KH * d->KW;
     int T;

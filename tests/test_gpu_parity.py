@@ -167,6 +167,10 @@ def _oracle_conv_case(N, Cin, Cout, Hh, Ww, k, stride, pad, seed, transposed=Fal
     (1, 48, 3, 24, 40, 3, 1, 1),       # head conv Cout=3 (KC=16)
     (1, 16, 1, 24, 40, 1, 1, 0),       # detail 1x1 conv
     (1, 24, 8, 16, 32, 3, 1, 1),       # KC=8 path
+    (2, 96, 96, 12, 64, 3, 1, 1),      # row-split weight gradient, 27 accumulator tiles, image seams inside a split
+    (3, 64, 64, 8, 96, 3, 1, 1),       # row-split, TN=2, interior + edge tiles
+    (2, 32, 192, 16, 128, 4, 2, 1),    # row-split k4 s2: four kernel-parity sub-launches, TN=3
+    (1, 96, 64, 24, 64, 4, 2, 1),      # row-split k4 s2, TN=2
 ])
 def test_conv_forward_dgrad_wgrad_vs_oracle(N, Cin, Cout, Hh, Ww, k, stride, pad):
     x, w, b = _oracle_conv_case(N, Cin, Cout, Hh, Ww, k, stride, pad, seed=Cin * 1000 + Cout)
@@ -195,7 +199,9 @@ def test_conv_forward_dgrad_wgrad_vs_oracle(N, Cin, Cout, Hh, Ww, k, stride, pad
     assert rel_err(eng.param_grads[id(bd)], br.grad) < 1e-4
 
 
-@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww", [(1, 384, 96, 12, 20), (2, 64, 32, 9, 17), (1, 256, 128, 8, 16)])
+@pytest.mark.parametrize("N,Cin,Cout,Hh,Ww", [(1, 384, 96, 12, 20), (2, 64, 32, 9, 17), (1, 256, 128, 8, 16),
+                                              (2, 64, 96, 8, 64),      # row-split weight gradient (reversed 2x2 taps)
+                                              (1, 32, 64, 12, 32)])
 def test_conv_transpose_vs_oracle(N, Cin, Cout, Hh, Ww):
     x, w, b = _oracle_conv_case(N, Cin, Cout, Hh, Ww, 4, 2, 1, seed=Cin + Cout, transposed=True)
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)

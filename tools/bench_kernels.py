@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--pass", dest="passes", default="fwd,dgrad,wgrad", help="comma list of fwd,dgrad,wgrad")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     N = args.batch
@@ -79,7 +80,7 @@ def main():
             eng._wgrad(eng._launch_plan(kind, k, stride, pad, w, "fwd"), x, g, Cout, w)
 
         for tag, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
-            if name == "stem7x7" and tag == "dgrad":
+            if (name == "stem7x7" and tag == "dgrad") or tag not in args.passes.split(","):
                 continue
             ms = timeit(fn, args.iters)
             print(f"{name:18s} {tag:6s} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s ({flops / 1e9:.0f} GFLOP)", flush=True)
