@@ -6,49 +6,87 @@
 //
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
 //
-// Workgroup = 512 threads: output region 8 rows x 32 cols = 4 x 16 Winograd tiles (two 32-tile MFMA row blocks)
-// x 32 output channels.
-//   waves 4-7 (producers): stage the region's raw 10x34-pixel halo of the next 16-channel chunk in LDS (coalesced,
-//       each input element fetched once), then one (tile, channel quad) per thread: read the 4x4x4 patch from the
-//       raw tile, apply B^T d B in registers, write the 16 frequency planes to LDS
-//       V[buf][freq][cquad][tile][4]  (16-byte tile pitch: conflict-free ds_read_b128 for the MFMA operand);
-//   waves 0-3 (consumers): 4 of the 16 frequencies each; per chunk of 16 input channels 64 MFMAs against the
-//       transformed weights U[freq][k/4][n][4] read straight from global/L2.  Two barriers per chunk (raw tile
-//       written | patches transformed); V is double buffered so chunk c+1 is produced while chunk c is contracted.
-//   epilogue: accumulators -> LDS M[freq][tile][co], all 512 threads apply A^T M A and the fused epilogue.
+// Design rules (measured, tools/micro/): on gfx950 a VALU instruction takes its issue cycles away from the fp32
+// MFMA pipe of the same SIMD -- they do not overlap -- while LDS reads, LDS-DMA and a few global loads per MFMA
+// are free.  So there are no producer waves: four waves (one per SIMD, 512 registers each) all run the same
+// stream, the MFMA loops carry no vector ALU work, and every byte is staged by instructions that need no VALU.
+//
+// Workgroup = 256 threads: output region 8 rows x 32 cols = 4 x 16 Winograd tiles (two 32-tile MFMA row
+// blocks) x 32*NT output channels; wave w owns the four frequencies (w, 0..3) of all of them: 8*NT 32x32
+// accumulator tiles, the first 16 pinned to AGPRs and the rest to VGPRs.
+// Per chunk of 16 input channels:
+//   * raw halo 10 x 34 pixels x 16 ch -> LDS by LDS-DMA, laid out [row][column parity][16 px][16 ch] (+ the two
+//     right-most columns in a per-row tail) so that the 4x4 patch reads of the transform are conflict-free;
+//   * transform: thread (tile, channel quad) reads its patch (16 ds_read_b128), applies B^T d B in registers and
+//     writes the 16 frequency planes V[f][tile][quad slot ^ swizzle(tile)] (conflict-free both for these writes
+//     and for the ds_read_b128 MFMA operand reads);
+//   * contraction: 8 groups (4 frequencies x two 8-channel halves) of 8*NT MFMAs; per group two ds_read_b128
+//     (A) and NT global_load_dwordx4 (B = transformed weights U[f][k/4][n][4], L2 resident), both fetched one
+//     group ahead; addresses are immediates / scalar, waits are counted by hand.
+// V is double buffered (chunk c+1 is transformed between the two halves of chunk c's contraction); the raw tile
+// is single buffered: two barriers per chunk.
+// Epilogue: accumulators -> LDS M[freq][tile][co] (one 32-channel tile at a time), all threads apply A^T M A
+// and the fused epilogue.
 #include "common.h"
+#include <cstdlib>
 
-#define WN_KC 16                 // input channels per chunk
-#define WN_TILES 64              // Winograd tiles per workgroup
-#define WN_VBUF (16 * (WN_KC / 4) * WN_TILES)   // float4 per V buffer (65536 B)
-#define WN_RAW_W 34
-#define WN_RAW_PX (10 * WN_RAW_W)               // raw halo pixels of one 8x32 region
-#define WN_RAW_IT 6                             // ceil(340 * 4 / 256) float4 per producer thread
+#define W2_KC 16
+#define W2_TILES 64
+#define W2_VBUF_F (16 * W2_TILES * W2_KC)          // floats per V buffer (64 KB)
+#define W2_RAW_PITCH 576                           // floats per raw row: [2][16 px][16 ch] + 64 tail floats
+#define W2_RAW_F (10 * W2_RAW_PITCH)
+#define W2_LDS_BYTES ((2 * W2_VBUF_F + W2_RAW_F) * 4)
 
-// Weight prefetch outside hipcc's waitcnt bookkeeping (cdna_hip_programming.md 5.7): hipcc waits for a plain
-// prefetch at the first MFMA of the SAME chunk (a conservative vmcnt on the loop-carried register set), exposing the
-// L2 latency every chunk.  The asm load is invisible to that pass; wait_b() is the hand-placed wait, naming every
-// destination so no consumer is scheduled above it.  The consumer waves issue no other vector-memory operation
-// inside the chunk loop, so vmcnt(0) there waits exactly for the set issued one chunk earlier.
-__device__ __forceinline__ void gload_b128(f32x4& dst, const f32x4* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void wait_b(f32x4 (&b)[4][2]) {
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]),
-                   "+v"(b[3][1])
-                 :
-                 : "memory");
-}
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 struct WinoGeom {
     int tiles_x, tiles_y;        // 32-col x 8-row regions
+    int nregions;
     int nchunks;
     int KQtot;                   // Cin / 4
+    int ncog;                    // output-channel groups of 32*NT
+    int dbg;                     // ADH_WINO_DEBUG bits (ablation runs only): 1 no epilogue, 2 no transform
 };
 
-__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const adh_conv_desc d, const WinoGeom g) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];   // V[2][16][KC/4][64] ; reused as M[16][64][32] floats
+// accumulator tile IDX of a wave: first 16 in AGPRs, rest in VGPRs (see conv_wgrad.hip, wr_mfma)
+template <int IDX>
+__device__ __forceinline__ void w2_mfma(f32x16& c, float a, float b) {
+    if constexpr (IDX < 16) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// one contraction group: local frequency F, both tile halves, NT output-channel tiles, 4 k-steps
+template <int NT, int F, int KK, int TH, int J>
+__device__ __forceinline__ void w2_group(f32x16 (&acc)[8 * NT], const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
+    if constexpr (KK < 4) {
+        w2_mfma<(F * 2 + TH) * NT + J>(acc[(F * 2 + TH) * NT + J], a[TH][KK], b[J][KK]);
+        if constexpr (J + 1 < NT) w2_group<NT, F, KK, TH, J + 1>(acc, a, b);
+        else if constexpr (TH == 0) w2_group<NT, F, KK, 1, 0>(acc, a, b);
+        else w2_group<NT, F, KK + 1, 0, 0>(acc, a, b);
+    }
+}
+
+// Weight fetch outside hipcc's waitcnt bookkeeping (hipcc would wait for a plain prefetch at the first MFMA of the
+// same group); scalar base + per-lane 32-bit offset + immediate: no address VALU.
+template <int NT>
+__device__ __forceinline__ void w2_load_b(f32x4 (&b)[NT], unsigned voff, const float* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(voff), "s"(sbase) : "memory");
+    if constexpr (NT > 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(b[1]) : "v"(voff), "s"(sbase) : "memory");
+    if constexpr (NT > 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[2]) : "v"(voff), "s"(sbase) : "memory");
+}
+// wait until at most N vector-memory operations issued after `b`'s loads are outstanding; names b so that no
+// consumer is scheduled above the wait
+template <int N, int NT>
+__device__ __forceinline__ void w2_wait_b(f32x4 (&b)[NT]) {
+    if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b[0]) : "n"(N) : "memory");
+    if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+    if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N) : "memory");
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const adh_conv_desc d, const WinoGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // V[2][16][64][16] | raw[10][576]; V reused as M[16][64][32]
+    float* const raw = lds + 2 * W2_VBUF_F;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -56,241 +94,343 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const adh_conv_desc d
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    int reg = blockIdx.x;
-    const int tx = reg % g.tiles_x;
-    reg /= g.tiles_x;
-    const int ty = reg % g.tiles_y;
-    const int n = reg / g.tiles_y;
+    // XCD-aware decode: the workgroups that read one input region (one per output-channel group) land on one XCD
+    const int bid = blockIdx.x;
+    const int q = bid >> 3;
+    const int cg = q % g.ncog;
+    const int region = (q / g.ncog) * 8 + (bid & 7);
+    if (region >= g.nregions) return;
+    int rr = region;
+    const int tx = rr % g.tiles_x;
+    rr /= g.tiles_x;
+    const int ty = rr % g.tiles_y;
+    const int n = rr / g.tiles_y;
     const int oy0 = ty * 8, ox0 = tx * 32;
-    const int co0 = blockIdx.y * 32;
+    const int co0 = cg * 32 * NT;
 
-    f32x4* raw = lds + 2 * WN_VBUF;   // [KC/4][340 pixels] float4
-    if (wave >= 4) {
-        // ------------------------------------------------------------------ producers
-        const int pt = tid - 256;
-        // one producer wave per channel quad, lanes = the 64 tiles: the V writes of a wave are 64 consecutive
-        // 16-B slots (conflict free); the raw tile is quad-major so the patch reads are at worst 2-way
-        const int tile = pt & 63, cq = pt >> 6;
-        const int trow = tile >> 4, tcol = tile & 15;
-        const float* in_n = d.in + (size_t)n * d.IH * d.IW * d.in_cstride;
-        // raw staging plan: float4 #item = pixel*4 + cquad of the 10x34 halo (origin oy0-1, ox0-1)
-        int goff[WN_RAW_IT];
+    // ------------------------------------------------------------------ raw halo staging plan (LDS-DMA)
+    // 32 pieces per chunk, 8 per wave (piece j = 4u + wave): j < 20 full pieces (row j/2, column parity j&1, 16 pixels x
+    // 16 ch), 20 <= j < 30 the tail of row j-20 (columns 32, 33 in lanes 0-7; lanes 8-15 re-read column 0 into the
+    // pad so the instruction always issues), j >= 30 repeat pieces 28, 29: every wave issues exactly 8 per chunk,
+    // which is what the hand-counted vmcnt waits below rely on.  Out-of-image rows are fetched from the clamped row
+    // and zeroed after they land; out-of-image columns are lane-masked and zeroed.
+    const int xcs = d.in_cstride * 4;                                    // pixel pitch in bytes
+    const float* xbase = d.in + (int64_t)n * d.IH * d.IW * d.in_cstride - d.in_cstride;   // pixel (0, -1) of image n
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, 0x7fffffff, 0x00020000);
+    const int cq_l = lane & 3, px_l = lane >> 2;
+    const int vfull = 2 * px_l * xcs + cq_l * 16;                          // + parity * xcs (scalar)
+    const int vtail = (lane < 8 ? (32 + (px_l & 1)) : 1) * xcs + cq_l * 16;
+    const bool interior = oy0 >= 1 && oy0 + 8 < d.IH && ox0 >= 1 && ox0 + 33 < d.IW;
+    int p_dst[8], p_so[8];      // LDS float offset in raw; scalar byte offset without the chunk term
+    bool p_tail[8], p_par[8], p_rowok[8];
 #pragma unroll
-        for (int it = 0; it < WN_RAW_IT; ++it) {
-            const int item = pt + it * 256;
-            int o = -1;
-            if (item < WN_RAW_PX * 4) {
-                const int pix = item >> 2, q = item & 3;
-                const int hy = pix / WN_RAW_W, hx = pix - hy * WN_RAW_W;
-                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-                if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) o = (iy * d.IW + ix) * d.in_cstride + q * 4;
-            }
-            goff[it] = o;
-        }
-        f32x4 rr[WN_RAW_IT];
-        auto load_raw = [&](int c) {
-            const float* base = in_n + c * WN_KC;
+    for (int u = 0; u < 8; ++u) {
+        int j = 4 * u + wave;
+        if (j >= 30) j -= 2;
+        p_tail[u] = j >= 20;
+        const int row = p_tail[u] ? j - 20 : j >> 1;
+        p_par[u] = !p_tail[u] && (j & 1);
+        const int iy = oy0 - 1 + row;
+        p_rowok[u] = iy >= 0 && iy < d.IH;
+        const int iyc = adh_min_i(adh_max_i(iy, 0), d.IH - 1);
+        p_dst[u] = row * W2_RAW_PITCH + (p_tail[u] ? 512 : (p_par[u] ? 256 : 0));
+        p_so[u] = (iyc * d.IW + ox0 + (p_par[u] ? 1 : 0)) * xcs;
+    }
+    // per-lane validity of the columns a full (parity 0 / 1) or tail piece covers
+    const int ix_f = ox0 - 1 + 2 * px_l;            // + parity
+    const bool ok_f0 = ix_f >= 0 && ix_f < d.IW, ok_f1 = ix_f + 1 < d.IW;
+    const bool ok_t = lane < 8 ? (ox0 + 31 + (px_l & 1) < d.IW) : (lane < 16);
+    auto stage_raw = [&](int c) {
+        const int cb = c * (W2_KC * 4);
+        if (interior) {
 #pragma unroll
-            for (int it = 0; it < WN_RAW_IT; ++it) {
-                // unconditional load (out-of-image lanes read the tensor base and are zeroed when stored), so the six
-                // loads stay in flight across the next barrier instead of being waited for here
-                rr[it] = *reinterpret_cast<const f32x4*>(goff[it] >= 0 ? base + goff[it] : in_n);
-            }
-        };
-        auto store_raw = [&]() {
-#pragma unroll
-            for (int it = 0; it < WN_RAW_IT; ++it) {
-                const int item = pt + it * 256;
-                if (item < WN_RAW_PX * 4)
-                    raw[(item & 3) * WN_RAW_PX + (item >> 2)] = goff[it] >= 0 ? rr[it] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        };
-        const f32x4* patch = raw + cq * WN_RAW_PX + (2 * trow) * WN_RAW_W + 2 * tcol;
-        auto transform = [&](int c) {
-            f32x4 t[16];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {      // rows:  B^T d
-                const f32x4 d0 = patch[0 * WN_RAW_W + b], d1 = patch[1 * WN_RAW_W + b];
-                const f32x4 d2 = patch[2 * WN_RAW_W + b], d3 = patch[3 * WN_RAW_W + b];
-                t[0 * 4 + b] = d0 - d2;
-                t[1 * 4 + b] = d1 + d2;
-                t[2 * 4 + b] = d2 - d1;
-                t[3 * 4 + b] = d1 - d3;
-            }
-            f32x4* Vb = lds + (c & 1) * WN_VBUF + cq * WN_TILES + tile;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {      // columns: (B^T d) B
-                Vb[(a * 4 + 0) * (WN_KC / 4) * WN_TILES] = t[a * 4 + 0] - t[a * 4 + 2];
-                Vb[(a * 4 + 1) * (WN_KC / 4) * WN_TILES] = t[a * 4 + 1] + t[a * 4 + 2];
-                Vb[(a * 4 + 2) * (WN_KC / 4) * WN_TILES] = t[a * 4 + 2] - t[a * 4 + 1];
-                Vb[(a * 4 + 3) * (WN_KC / 4) * WN_TILES] = t[a * 4 + 1] - t[a * 4 + 3];
-            }
-        };
-        // prologue: chunk 0 through the raw tile, chunk 1 already in flight
-        load_raw(0);
-        store_raw();
-        if (g.nchunks > 1) load_raw(1);
-        __syncthreads();       // P: raw(0) complete
-        transform(0);
-        __syncthreads();       // b_0: V[0] visible
-        for (int c = 0; c < g.nchunks; ++c) {
-            // consumers contract chunk c; meanwhile produce chunk c+1
-            if (c + 1 < g.nchunks) store_raw();              // raw(c+1) from the registers loaded one interval ago
-            if (c + 2 < g.nchunks) load_raw(c + 2);
-            __syncthreads();   // m_c: raw(c+1) complete
-            if (c + 1 < g.nchunks) transform(c + 1);
-            __syncthreads();   // b_{c+1}: V[(c+1)&1] visible (after the last chunk: E1, everyone done with V)
-        }
-        __syncthreads();       // E2: accumulators are in LDS
-    } else {
-        // ------------------------------------------------------------------ consumers
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int fl = 0; fl < 4; ++fl)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[fl][mb][r] = 0.f;
-        const f32x4* U4 = reinterpret_cast<const f32x4*>(d.wp);
-        f32x4 bA[4][2], bB[4][2];   // two weight register sets, ping-ponged over an unrolled-by-two chunk loop
-        auto fetch_b = [&](int c, f32x4 (&b)[4][2]) {
-#pragma unroll
-            for (int fl = 0; fl < 4; ++fl)
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg)
-                    gload_b128(b[fl][gg],
-                               U4 + (size_t)((wave * 4 + fl) * g.KQtot + c * (WN_KC / 4) + 2 * gg + h) * d.NcP + co0 + l31);
-        };
-        auto contract = [&](int c, const f32x4 (&bw)[4][2]) {
-            const f32x4* Vb = lds + (c & 1) * WN_VBUF + h * WN_TILES + l31;
-            // 4 double steps: two frequencies x one channel group each, i.e. 16 MFMAs on FOUR accumulators issued
-            // round-robin (dependent MFMAs are 4 issue slots apart); the LDS operands of double step s+1 are read
-            // before the MFMAs of double step s issue
-            auto rd = [&](int ds, f32x4 (&a)[4]) {
-                const int p = ds >> 1, gg = ds & 1;
-                const f32x4* v0 = Vb + ((wave * 4 + 2 * p) * (WN_KC / 4) + 2 * gg) * WN_TILES;
-                const f32x4* v1 = v0 + (WN_KC / 4) * WN_TILES;
-                a[0] = v0[0];
-                a[1] = v0[32];
-                a[2] = v1[0];
-                a[3] = v1[32];
-            };
-            f32x4 ac[4], an[4];
-            rd(0, ac);
-#pragma unroll
-            for (int ds = 0; ds < 4; ++ds) {
-                const int p = ds >> 1, gg = ds & 1;
-                if (ds == 1) __syncthreads();   // m_c
-                if (ds < 3) rd(ds + 1, an);
-                __builtin_amdgcn_sched_barrier(0);
-                const f32x4 b0 = bw[2 * p][gg], b1 = bw[2 * p + 1][gg];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[2 * p][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0][j], b0[j], acc[2 * p][0], 0, 0, 0);
-                    acc[2 * p][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[1][j], b0[j], acc[2 * p][1], 0, 0, 0);
-                    acc[2 * p + 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[2][j], b1[j], acc[2 * p + 1][0], 0, 0, 0);
-                    acc[2 * p + 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[3][j], b1[j], acc[2 * p + 1][1], 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                if (p_tail[u]) {
+                    if (lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + p_dst[u]), 16, vtail, p_so[u] + cb, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + p_dst[u]), 16, vfull, p_so[u] + cb, 0, 0);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ac[i] = an[i];
             }
-            __syncthreads();   // b_{c+1} (E1 after the last chunk)
-        };
-        fetch_b(0, bA);
-        __syncthreads();       // P
-        __syncthreads();       // b_0
-        for (int c = 0; c < g.nchunks; c += 2) {
-            wait_b(bA);                                   // issued one chunk ago: already landed
-            if (c + 1 < g.nchunks) fetch_b(c + 1, bB);   // next chunk's weights stay in flight during this contraction
-            __builtin_amdgcn_sched_barrier(0);
-            contract(c, bA);
-            if (c + 1 < g.nchunks) {
-                wait_b(bB);
-                if (c + 2 < g.nchunks) fetch_b(c + 2, bA);
-                __builtin_amdgcn_sched_barrier(0);
-                contract(c + 1, bB);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = p_tail[u] ? ok_t : (p_par[u] ? ok_f1 : ok_f0);
+                const int vo = p_tail[u] ? vtail : vfull;
+                if (ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + p_dst[u]), 16, vo, p_so[u] + cb, 0, 0);
             }
         }
-        float* M = reinterpret_cast<float*>(lds);   // [16][64][32]
+    };
+    // zero what the padding semantics require (edge regions only; runs after this wave's pieces have landed)
+    auto fix_raw = [&]() {
+        if (interior) return;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int fl = 0; fl < 4; ++fl)
+        for (int u = 0; u < 8; ++u) {
+            float* dst = raw + p_dst[u] + lane * 4;
+            const bool ok = p_tail[u] ? ok_t : (p_par[u] ? ok_f1 : ok_f0);
+            const bool mine = p_tail[u] ? lane < 8 : true;
+            if (mine && !(p_rowok[u] && ok)) *reinterpret_cast<f32x4*>(dst) = z;
+        }
+    };
+
+    // ------------------------------------------------------------------ input transform: thread = (tile, channel quad)
+    const int tcol = lane >> 2;          // tile row = wave
+    const int tile_t = wave * 16 + tcol;
+    int colb[4];
+    colb[0] = tcol * 16;
+    colb[1] = 256 + tcol * 16;
+    colb[2] = tcol < 15 ? (tcol + 1) * 16 : 512;
+    colb[3] = tcol < 15 ? 256 + (tcol + 1) * 16 : 512 + 16;
+    const float* patch = raw + (2 * wave) * W2_RAW_PITCH + cq_l * 4;
+    const int vslot_t = tile_t * 16 + ((cq_l ^ ((tile_t >> 1) & 3)) * 4);
+    auto transform = [&](int buf) {
+        f32x4 t[16];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+        for (int b = 0; b < 4; ++b) {      // rows:  B^T d
+            const float* pc = patch + colb[b];
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(pc + 0 * W2_RAW_PITCH);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(pc + 1 * W2_RAW_PITCH);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(pc + 2 * W2_RAW_PITCH);
+            const f32x4 d3 = *reinterpret_cast<const f32x4*>(pc + 3 * W2_RAW_PITCH);
+            t[0 * 4 + b] = d0 - d2;
+            t[1 * 4 + b] = d1 + d2;
+            t[2 * 4 + b] = d2 - d1;
+            t[3 * 4 + b] = d1 - d3;
+        }
+        float* Vb = lds + buf * W2_VBUF_F + vslot_t;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int t = (r & 3) + 8 * (r >> 2) + 4 * h + 32 * mb;
-                    M[((wave * 4 + fl) * WN_TILES + t) * 32 + l31] = acc[fl][mb][r];
-                }
-        __syncthreads();       // E2
+        for (int a = 0; a < 4; ++a) {      // columns: (B^T d) B
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 0) * 1024) = t[a * 4 + 0] - t[a * 4 + 2];
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 1) * 1024) = t[a * 4 + 1] + t[a * 4 + 2];
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 2) * 1024) = t[a * 4 + 2] - t[a * 4 + 1];
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 3) * 1024) = t[a * 4 + 1] - t[a * 4 + 3];
+        }
+    };
+
+    // ------------------------------------------------------------------ contraction operands
+    // A: V[buf][F = 4*wave + f][tile = 32*th + l31][slot(2g + h)], slot(q) = q ^ ((tile >> 1) & 3); g flips slot bit 1
+    const int sw = (l31 >> 1) & 3;
+    const int a_lane = (wave * 4) * 1024 + l31 * 16 + ((h ^ sw) * 4);           // floats, g = 0
+    // B: U[F][kq = 4c + 2g + h][n = co0 + 32 j + l31] (float4)
+    const unsigned b_voff = (unsigned)((h * d.NcP + l31) * 16);
+    const float* const b_wave = d.wp + ((int64_t)(wave * 4) * g.KQtot * d.NcP + co0) * 4;
+    const int64_t b_fstride = (int64_t)g.KQtot * d.NcP * 4;                        // floats per frequency
+    const int b_kqstride = d.NcP * 4;                                              // floats per channel quad
+
+    f32x16 acc[8 * NT];
+#pragma unroll
+    for (int t = 0; t < 8 * NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    f32x4 av[2][2], bv[2][NT];
+    auto load_a = [&](const float* vb, int f, int gg, f32x4 (&a)[2]) {
+        const float* p = vb + f * 1024 + (gg ? (a_lane ^ 8) : a_lane);
+        a[0] = *reinterpret_cast<const f32x4*>(p);
+        a[1] = *reinterpret_cast<const f32x4*>(p + 512);
+    };
+    auto b_ptr = [&](int c, int f, int gg) { return b_wave + f * b_fstride + (int64_t)(c * 4 + 2 * gg) * b_kqstride; };
+
+    // ------------------------------------------------------------------ prologue
+    w2_load_b<NT>(bv[0], b_voff, b_ptr(0, 0, 0));
+    stage_raw(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fix_raw();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    transform(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll 1
+    for (int c = 0; c < g.nchunks; ++c) {
+        const float* vb = lds + (c & 1) * W2_VBUF_F;
+        const bool more = c + 1 < g.nchunks;
+        const int cn = more ? c + 1 : c;   // the last chunk re-issues its own (harmless) loads: uniform counts
+        load_a(vb, 0, 0, av[0]);
+        // ---- groups 0..3: channel half g = 0
+        w2_load_b<NT>(bv[1], b_voff, b_ptr(c, 1, 0));
+        stage_raw(cn);
+        load_a(vb, 1, 0, av[1]);
+        w2_wait_b<NT + 8, NT>(bv[0]);
+        w2_group<NT, 0, 0, 0, 0>(acc, av[0], bv[0]);
+
+        w2_load_b<NT>(bv[0], b_voff, b_ptr(c, 2, 0));
+        load_a(vb, 2, 0, av[0]);
+        w2_wait_b<NT + 8, NT>(bv[1]);
+        w2_group<NT, 1, 0, 0, 0>(acc, av[1], bv[1]);
+
+        w2_load_b<NT>(bv[1], b_voff, b_ptr(c, 3, 0));
+        load_a(vb, 3, 0, av[1]);
+        w2_wait_b<NT, NT>(bv[0]);            // also retires this wave's 8 raw pieces (in-order return)
+        w2_group<NT, 2, 0, 0, 0>(acc, av[0], bv[0]);
+
+        w2_load_b<NT>(bv[0], b_voff, b_ptr(c, 0, 1));
+        load_a(vb, 0, 1, av[0]);
+        w2_wait_b<NT, NT>(bv[1]);
+        w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
+        // ---- raw(c+1) complete -> transform into the other V buffer
+        fix_raw();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more && !(g.dbg & 2)) transform((c + 1) & 1);
+        // ---- groups 4..7: channel half g = 1
+        w2_load_b<NT>(bv[1], b_voff, b_ptr(c, 1, 1));
+        load_a(vb, 1, 1, av[1]);
+        w2_wait_b<NT, NT>(bv[0]);
+        w2_group<NT, 0, 0, 0, 0>(acc, av[0], bv[0]);
+
+        w2_load_b<NT>(bv[0], b_voff, b_ptr(c, 2, 1));
+        load_a(vb, 2, 1, av[0]);
+        w2_wait_b<NT, NT>(bv[1]);
+        w2_group<NT, 1, 0, 0, 0>(acc, av[1], bv[1]);
+
+        w2_load_b<NT>(bv[1], b_voff, b_ptr(c, 3, 1));
+        load_a(vb, 3, 1, av[1]);
+        w2_wait_b<NT, NT>(bv[0]);
+        w2_group<NT, 2, 0, 0, 0>(acc, av[0], bv[0]);
+
+        w2_load_b<NT>(bv[0], b_voff, b_ptr(cn, 0, 0));
+        w2_wait_b<NT, NT>(bv[1]);
+        w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    w2_wait_b<0, NT>(bv[0]);   // the trailing (dummy) weight fetch
+    if (g.dbg & 1) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8 * NT; ++t) s += acc[t][0];
+        if (s == 123.456f) d.out[tid] = s;
+        return;
     }
 
     // ---------------------------------------------------------------------- output transform + fused epilogue
-    const float* M = reinterpret_cast<const float*>(lds);
+    float* M = lds;   // [16][64][32]
     const int cl = tid & 31;
-    const int co = co0 + cl;
-    const bool cvalid = co < d.Cout;
-    const float sc = (d.scale && cvalid) ? d.scale[co] : 1.f;
-    const float sh = (d.shift && cvalid) ? d.shift[co] : 0.f;
     float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
     const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
-    float ssum = 0.f, ssq = 0.f;
+    float* red = raw;   // [2][8][32] statistics exchange (the raw tile is idle now)
+    const bool full = oy0 + 8 <= d.OH && ox0 + 32 <= d.OW && co0 + 32 * NT <= d.Cout;
+    const int ocs = d.out_cstride * 4, rcs = d.res_cstride * 4;
+    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(out_n, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr_ =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res_n ? res_n : d.in), 0, 0x7fffffff, 0x00020000);
+    const int ovoff = 2 * (tid >> 5) * ocs + cl * 4, rvoff = 2 * (tid >> 5) * rcs + cl * 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int t = (tid >> 5) + 16 * p;
-        const int trow = t >> 4, tcol = t & 15;
-        float m[16];
+    for (int j = 0; j < NT; ++j) {
+        if (j) __builtin_amdgcn_s_barrier();   // previous tile's M fully consumed
 #pragma unroll
-        for (int f = 0; f < 16; ++f) m[f] = M[(f * WN_TILES + t) * 32 + cl];
-        float s0[4], s1[4];
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            s0[b] = m[0 * 4 + b] + m[1 * 4 + b] + m[2 * 4 + b];
-            s1[b] = m[1 * 4 + b] - m[2 * 4 + b] - m[3 * 4 + b];
-        }
-        float y[2][2];
-        y[0][0] = s0[0] + s0[1] + s0[2];
-        y[0][1] = s0[1] - s0[2] - s0[3];
-        y[1][0] = s1[0] + s1[1] + s1[2];
-        y[1][1] = s1[1] - s1[2] - s1[3];
-        float rv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        if (res_n) {
+            for (int th = 0; th < 2; ++th)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int oy = oy0 + 2 * trow + a, ox = ox0 + 2 * tcol + b;
-                    const bool ok = cvalid && oy < d.OH && ox < d.OW;
-                    rv[a][b] = res_n[ok ? ((size_t)oy * d.OW + ox) * d.res_cstride + co : 0];
+                for (int r = 0; r < 16; ++r) {
+                    const int t = (r & 3) + 8 * (r >> 2) + 4 * h + 32 * th;
+                    M[((wave * 4 + f) * W2_TILES + t) * 32 + l31] = acc[(f * 2 + th) * NT + j][r];
                 }
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int co = co0 + j * 32 + cl;
+        const bool cvalid = co < d.Cout;
+        const float sc = (d.scale && cvalid) ? d.scale[co] : 1.f;
+        const float sh = (d.shift && cvalid) ? d.shift[co] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
+        if (full) {
+            // whole region inside the image, all 32 channels real: no predicates, and every global address is the
+            // per-thread constant voffset plus a scalar offset (buffer instructions: no address VALU)
+            const int cbytes = (co0 + j * 32) * 4;
+            // residual values are fetched one tile ahead of their use
+            float rv[2][2][2] = {};
+            auto load_res = [&](int p, float (&r)[2][2]) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int oy = oy0 + 2 * trow + a, ox = ox0 + 2 * tcol + b;
-                if (cvalid && oy < d.OH && ox < d.OW) {
-                    float v = y[a][b] * sc + sh;
-                    ssum += v;
-                    ssq += v * v;
-                    const size_t pix = (size_t)oy * d.OW + ox;
-                    if (res_n) v += rv[a][b];
-                    if (d.act == ADH_ACT_RELU) v = fmaxf(v, 0.f);
-                    out_n[pix * d.out_cstride + co] = v;
+                    for (int b = 0; b < 2; ++b)
+                        r[a][b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            rr_, rvoff, ((oy0 + 2 * (p >> 1) + a) * d.OW + ox0 + 16 * (p & 1) + b) * rcs + cbytes, 0));
+            };
+            if (res_n) load_res(0, rv[0]);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int t = (tid >> 5) + 8 * p;
+                float m[16];
+#pragma unroll
+                for (int f = 0; f < 16; ++f) m[f] = M[(f * W2_TILES + t) * 32 + cl];
+                if (res_n && p + 1 < 8) load_res(p + 1, rv[(p + 1) & 1]);
+                float s0[4], s1[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    s0[b] = m[0 * 4 + b] + m[1 * 4 + b] + m[2 * 4 + b];
+                    s1[b] = m[1 * 4 + b] - m[2 * 4 + b] - m[3 * 4 + b];
                 }
+                float y[2][2];
+                y[0][0] = s0[0] + s0[1] + s0[2];
+                y[0][1] = s0[1] - s0[2] - s0[3];
+                y[1][0] = s1[0] + s1[1] + s1[2];
+                y[1][1] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float v = y[a][b] * sc + sh;
+                        ssum += v;
+                        ssq += v * v;
+                        if (res_n) v += rv[p & 1][a][b];
+                        if (d.act == ADH_ACT_RELU) v = fmaxf(v, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(
+                            __float_as_uint(v), or_, ovoff, ((oy0 + 2 * (p >> 1) + a) * d.OW + ox0 + 16 * (p & 1) + b) * ocs + cbytes, 0);
+                    }
             }
-    }
-    if (d.stats) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(lds);   // [2][16][32]
-        red[(0 * 16 + (tid >> 5)) * 32 + cl] = ssum;
-        red[(1 * 16 + (tid >> 5)) * 32 + cl] = ssq;
-        __syncthreads();
-        if (tid < 64) {
-            const int which = tid >> 5;
-            float v = 0.f;
+        } else {
+#pragma unroll 1
+            for (int p = 0; p < 8; ++p) {
+                const int t = (tid >> 5) + 8 * p;
+                const int trow = t >> 4, tc = t & 15;
+                float m[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v += red[(which * 16 + r) * 32 + cl];
-            d.stats[((size_t)blockIdx.x * 2 + which) * d.NcP + co0 + cl] = v;
+                for (int f = 0; f < 16; ++f) m[f] = M[(f * W2_TILES + t) * 32 + cl];
+                float s0[4], s1[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    s0[b] = m[0 * 4 + b] + m[1 * 4 + b] + m[2 * 4 + b];
+                    s1[b] = m[1 * 4 + b] - m[2 * 4 + b] - m[3 * 4 + b];
+                }
+                float y[2][2];
+                y[0][0] = s0[0] + s0[1] + s0[2];
+                y[0][1] = s0[1] - s0[2] - s0[3];
+                y[1][0] = s1[0] + s1[1] + s1[2];
+                y[1][1] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int oy = oy0 + 2 * trow + a, ox = ox0 + 2 * tc + b;
+                        if (cvalid && oy < d.OH && ox < d.OW) {
+                            float v = y[a][b] * sc + sh;
+                            ssum += v;
+                            ssq += v * v;
+                            const size_t pix = (size_t)oy * d.OW + ox;
+                            if (res_n) v += res_n[pix * d.res_cstride + co];
+                            if (d.act == ADH_ACT_RELU) v = fmaxf(v, 0.f);
+                            out_n[pix * d.out_cstride + co] = v;
+                        }
+                    }
+            }
+        }
+        if (d.stats) {
+            if (j) __builtin_amdgcn_s_barrier();   // previous tile's partial sums fully read
+            red[(0 * 8 + (tid >> 5)) * 32 + cl] = ssum;
+            red[(1 * 8 + (tid >> 5)) * 32 + cl] = ssq;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < 64) {
+                const int which = tid >> 5;
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v += red[(which * 8 + r) * 32 + cl];
+                d.stats[((size_t)region * 2 + which) * d.NcP + co0 + j * 32 + cl] = v;
+            }
         }
     }
 }
@@ -299,9 +439,19 @@ extern "C" int adh_conv_wino_supported(const adh_conv_desc* d) {
     if (!d) return 0;
     if (d->KH != 3 || d->KW != 3 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1) return 0;
     if (d->out_oy != 0 || d->out_ox != 0 || d->dy0 != -1 || d->dx0 != -1 || d->dstep_y != 1 || d->dstep_x != 1) return 0;
-    if (d->Cin % WN_KC != 0 || d->in_cstride % 4 != 0) return 0;
+    if (d->Cin % W2_KC != 0 || d->in_cstride % 4 != 0) return 0;
     if (d->VH != d->OH || d->VW != d->OW || d->IH != d->OH || d->IW != d->OW) return 0;
     return 1;
+}
+
+template <int NT>
+static int launch_wino(hipStream_t s, const adh_conv_desc* d, WinoGeom g) {
+    g.ncog = d->NcP / (32 * NT);
+    const int nblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    hipLaunchKernelGGL((conv_wino_kernel<NT>), dim3(nblocks), dim3(256), W2_LDS_BYTES, s, *d, g);
+    return adh_check_launch();
 }
 
 extern "C" int adh_conv_wino_forward(void* stream, const adh_conv_desc* d) {
@@ -309,19 +459,21 @@ extern "C" int adh_conv_wino_forward(void* stream, const adh_conv_desc* d) {
     if (!d->in || !d->out || !d->wp || d->NcP % 32 != 0 || d->NcP < d->Cout) return ADH_E_ARG;
     if (d->out_cstride < d->Cout || (d->residual && d->res_cstride < d->Cout)) return ADH_E_ARG;
     if (((uintptr_t)d->in & 15) || ((uintptr_t)d->wp & 15)) return ADH_E_ARG;
-    if ((int64_t)d->IH * d->IW * d->in_cstride >= (1ll << 31) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 31))
+    if ((int64_t)(d->IH + 2) * d->IW * d->in_cstride >= (1ll << 29) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 31))
         return ADH_E_UNSUPPORTED;
     WinoGeom g;
     g.tiles_x = adh_ceil_div(d->OW, 32);
     g.tiles_y = adh_ceil_div(d->OH, 8);
-    g.nchunks = d->Cin / WN_KC;
+    g.nregions = g.tiles_x * g.tiles_y * d->N;
+    g.nchunks = d->Cin / W2_KC;
     g.KQtot = d->Cin / 4;
-    const int lds = 2 * WN_VBUF * 16 + WN_RAW_PX * (WN_KC / 4) * 16;   // V x2 (reused for the accumulator exchange) + raw tile
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    dim3 grid(g.tiles_x * g.tiles_y * d->N, d->NcP / 32);
-    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(512), lds, (hipStream_t)stream, *d, g);
-    return adh_check_launch();
+    const char* dbg = getenv("ADH_WINO_DEBUG");
+    g.dbg = dbg ? atoi(dbg) : 0;
+    const int nt = d->NcP / 32;
+    hipStream_t s = (hipStream_t)stream;
+    if (nt % 3 == 0) return launch_wino<3>(s, d, g);
+    if (nt % 2 == 0) return launch_wino<2>(s, d, g);
+    return launch_wino<1>(s, d, g);
 }
 
 // U[f = a*4+b][k/4][n][4] = (G g G^T)[a][b] for every (k, n); g taken through the same adh_wlayout as the direct

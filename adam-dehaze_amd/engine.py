@@ -22,6 +22,7 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 # Winograd F(2x2,3x3) for eligible 3x3 stride-1 convolutions and their data gradients (ADH_WINOGRAD=0 disables)
 USE_WINOGRAD = os.environ.get("ADH_WINOGRAD", "1") != "0"
+_WINO_ONLY = os.environ.get("ADH_WINOGRAD_ONLY", "")   # dev: "fwd" or "dgrad" restricts the Winograd path to one direction
 
 
 def _round_up(a: int, b: int) -> int:
@@ -269,7 +270,8 @@ class Engine:
             d = self._conv_desc(src, Kp, dst_t, dstC, NcP, VH, VW, gm["KH"], gm["KW"], gm["in_s"], gm["out_s"],
                                 gm["out_o"], gm["dy0"], gm["dx0"], gm["dstep"])
             wino = False
-            if USE_WINOGRAD and gm["KH"] == 3 and gm["KW"] == 3 and gm["in_s"] == 1 and gm["out_s"] == 1 and Kp % 16 == 0 \
+            if USE_WINOGRAD and (not _WINO_ONLY or _WINO_ONLY == ("dgrad" if gm["dstep"] == -1 else "fwd")) \
+                    and gm["KH"] == 3 and gm["KW"] == 3 and gm["in_s"] == 1 and gm["out_s"] == 1 and Kp % 16 == 0 \
                     and (gm["dy0"], gm["dx0"], gm["dstep"]) in ((-1, -1, 1), (1, 1, -1)):
                 Lw = L
                 if gm["dstep"] == -1:   # data gradient: the same correlation with the filter flipped in both axes

@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against (a) the golden fixtures generated from the
 reference and (b) the CPU oracle on seeded inputs.  Tolerance: dehazed tensors / losses within 1e-3
 fp32 (BASELINE.json north_star); tests use 2e-4 for outputs and 2e-3 relative for gradients."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -113,8 +115,20 @@ BRANCHES = [
 ]
 
 
+@pytest.mark.parametrize("wino", [False, True], ids=["direct", "winograd"])
 @pytest.mark.parametrize("name,ctor", BRANCHES)
-def test_branches_vs_reference_fixtures(name, ctor):
+def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
+    """Whole branches against the fixtures generated from the reference (tools/gen_golden.py).
+
+    Parameter gradients are gated strictly (5e-3 of the tensor's scale, element-wise) on the direct convolution
+    path, whose accumulation order follows the reference closely.  The Winograd path computes the same
+    convolutions with different rounding (per-layer agreement with the direct kernels is checked to ~1e-6 in
+    test_conv_forward_dgrad_wgrad_vs_oracle and test_winograd_matches_direct_path); over a dozen BatchNorm layers
+    that becomes ~1e-5 on activations, enough to flip a ReLU whose input sits within 1e-5 of zero.  In these
+    deliberately tiny fixtures (a 7x11 bottleneck) one flipped element moves a weight gradient by a few per cent
+    (measured: tools/wino_debug3.py), so that path is gated on the relative L2 error plus a looser element bound."""
+    import adam_dehaze_amd.engine as E
+    monkeypatch.setattr(E, "USE_WINOGRAD", wino)
     rec = load_golden(name)
     m = _load_into(ctor(), rec)
     x = t(rec["x"]).to(DEV)
@@ -138,8 +152,15 @@ def test_branches_vs_reference_fixtures(name, ctor):
         g = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)
         scale = max(float(ref.abs().max()), 1e-8)
         err = float((g - ref).abs().max())
-        if not err < 5e-3 * scale + 2e-7:
-            bad.append((pname, err, scale))
+        rel2 = float((g - ref).norm() / max(float(ref.norm()), 1e-8))
+        if os.environ.get("ADH_TEST_VERBOSE"):
+            print(f"{name:16s} {pname:44s} max-abs/scale {err / scale:.2e}  rel-L2 {rel2:.2e}  scale {scale:.2e}")
+        if not wino or scale < 1e-6:   # (a bias feeding train-mode BatchNorm has a zero true gradient)
+            ok = err < 5e-3 * scale + 2e-7
+        else:
+            ok = rel2 < 3e-2 and err < 8e-2 * scale + 2e-7
+        if not ok:
+            bad.append((pname, err, scale, rel2))
     assert not bad, bad[:8]
     after = sub_sd(rec, "sd_after_train.")
     for k, v in m.state_dict().items():
@@ -279,3 +300,32 @@ def test_complex_fullwidth_vs_oracle_seeded():
     for k, v in m.state_dict().items():
         if "running" in k:
             assert max_abs(v, sd32[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 16, 16, 15, 23), (2, 32, 32, 7, 11), (1, 16, 48, 15, 23), (2, 96, 96, 16, 64),
+                                           (1, 64, 192, 24, 40), (3, 32, 16, 8, 96), (1, 16, 16, 41, 66)])
+def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, monkeypatch):
+    """Same layer through conv_wino_kernel and conv_igemm_kernel: outputs and BatchNorm partial statistics agree to
+    fp32 rounding, including ragged regions, channel tails (Co < 32) and the fused residual + ReLU epilogue."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(Ci * 31 + Hh)
+    x = torch.randn(N, Hh, Ww, Ci, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).to(DEV)
+    b = torch.randn(Co, generator=g).to(DEV)
+    res = torch.randn(N, Hh, Ww, Co, generator=g).to(DEV)
+    got = {}
+    for wino in (False, True):
+        monkeypatch.setattr(E, "USE_WINOGRAD", wino)
+        eng = Engine(torch.device(DEV), record=False)
+        plans = eng._launch_plan("conv", 3, 1, 1, w, "fwd")
+        y = torch.zeros(N, Hh, Ww, Co, device=DEV)
+        stats, nblk = eng._run_gather(plans, Act(x), y, Co, w, shift=b, want_stats=True)
+        y2 = torch.zeros(N, Hh, Ww, Co, device=DEV)
+        eng._run_gather(plans, Act(x), y2, Co, w, shift=b, residual=res, act=1)
+        torch.cuda.synchronize()
+        got[wino] = (y.cpu(), stats.view(nblk, 2, -1).double().sum(0)[:, :Co].cpu(), y2.cpu())
+    scale = float(got[False][0].abs().max())
+    assert max_abs(got[True][0], got[False][0]) < 4e-6 * scale
+    assert max_abs(got[True][2], got[False][2]) < 4e-6 * scale
+    ref_s = got[False][1]
+    assert float((got[True][1] - ref_s).abs().max()) < 2e-5 * float(ref_s.abs().max())
