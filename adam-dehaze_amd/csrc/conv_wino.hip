@@ -45,7 +45,7 @@ struct WinoGeom {
     int nchunks;
     int KQtot;                   // Cin / 4
     int ncog;                    // output-channel groups of 32*NT
-    int dbg;                     // ADH_WINO_DEBUG bits (ablation runs only): 1 no epilogue, 2 no transform
+    int dbg;                     // ADH_WINO_DEBUG bit 1 (ablation runs only): skip the epilogue
 };
 
 // accumulator tile IDX of a wave: first 16 in AGPRs, rest in VGPRs (see conv_wgrad.hip, wr_mfma)
@@ -66,8 +66,13 @@ __device__ __forceinline__ void w2_group(f32x16 (&acc)[8 * NT], const f32x4 (&a)
     }
 }
 
-// Weight fetch outside hipcc's waitcnt bookkeeping (hipcc would wait for a plain prefetch at the first MFMA of the
-// same group); scalar base + per-lane 32-bit offset + immediate: no address VALU.
+// Weight fetch outside hipcc's waitcnt bookkeeping; scalar base + per-lane 32-bit offset + immediate: no address
+// VALU.  Why asm: hipcc does not count LDS-DMA pieces in vmcnt, so with plain loads every wait it places after the
+// raw-tile DMA also drains the DMA (measured +4 % kernel time); the hand-counted waits below let the 8 pieces stay
+// in flight for two groups.  Contract (cdna_hip_programming.md 5.7): the destination registers must reach
+// w2_wait_b untouched -- keep the issue -> wait span free of control flow that could make the compiler copy them
+// (a run-time branch around the waits corrupted NT = 1, 2 in development; tests/test_gpu_parity.py::
+// test_winograd_matches_direct_path covers every NT with interior and edge regions).
 template <int NT>
 __device__ __forceinline__ void w2_load_b(f32x4 (&b)[NT], unsigned voff, const float* sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(voff), "s"(sbase) : "memory");
@@ -273,7 +278,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const adh_conv_desc d
         fix_raw();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (more && !(g.dbg & 2)) transform((c + 1) & 1);
+        // (unconditional: after the last chunk it fills the idle V buffer from the re-staged tile -- a branch here
+        // would sit between the asm weight fetch above and its wait, see w2_load_b)
+        transform((c + 1) & 1);
         // ---- groups 4..7: channel half g = 1
         w2_load_b<NT>(bv[1], b_voff, b_ptr(c, 1, 1));
         load_a(vb, 1, 1, av[1]);

@@ -303,7 +303,8 @@ def test_complex_fullwidth_vs_oracle_seeded():
 
 
 @pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 16, 16, 15, 23), (2, 32, 32, 7, 11), (1, 16, 48, 15, 23), (2, 96, 96, 16, 64),
-                                           (1, 64, 192, 24, 40), (3, 32, 16, 8, 96), (1, 16, 16, 41, 66)])
+                                           (1, 64, 192, 24, 40), (3, 32, 16, 8, 96), (1, 16, 16, 41, 66),
+                                           (1, 32, 64, 24, 96), (1, 96, 96, 40, 160), (1, 48, 32, 40, 128)])   # interior regions
 def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, monkeypatch):
     """Same layer through conv_wino_kernel and conv_igemm_kernel: outputs and BatchNorm partial statistics agree to
     fp32 rounding, including ragged regions, channel tails (Co < 32) and the fused residual + ReLU epilogue."""
