@@ -11,7 +11,9 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libadamdehaze_hip.so")
+# ADH_LIB_PATH: A/B runs of an alternative build of the same library (development only)
+_LIB_PATH = os.environ.get("ADH_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                           "libadamdehaze_hip.so")
 _lib: Optional[C.CDLL] = None
 
 ACT_NONE, ACT_RELU = 0, 1

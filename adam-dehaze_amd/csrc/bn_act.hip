@@ -93,25 +93,52 @@ extern "C" int adh_bn_fold_eval(void* stream, int C, const float* gamma, const f
 // ---------------------------------------------------------------------------------------------
 // apply: out = act(y*scale + shift (+ residual))
 // ---------------------------------------------------------------------------------------------
+// Streaming layout shared by the element-wise kernels below: the launch has T = gridDim.x * 256 threads with T a
+// multiple of CQ (channel quads per pixel), so a thread keeps one channel quad for the whole sweep -- its per-channel
+// constants are loaded once and no index division happens inside the loop -- and walks pixels p0, p0 + T/CQ, ...
+// four at a time (4-12 independent 16-byte loads in flight per lane: these kernels are HBM-bound).
+#define EW_UNROLL 8
+static int ew_blocks(int64_t P, int CQ) {
+    int g = CQ, r = 256;   // gcd(CQ, 256)
+    while (r) { const int t = g % r; g = r; r = t; }
+    const int mult = CQ / g;                                  // blocks must be a multiple of this
+    int64_t want = (P * CQ + 256 * EW_UNROLL - 1) / (256 * EW_UNROLL);
+    if (want > 256 * 8) want = 256 * 8;
+    int64_t blocks = (want + mult - 1) / mult * mult;
+    if (blocks < mult) blocks = mult;
+    return (int)blocks;
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int y_cs,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ residual, int res_cs, int act,
                                                        float* __restrict__ out, int out_cs, int64_t P, int CQ) {
-    const int64_t total = P * CQ;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = idx / CQ;
-        const int c = (int)(idx - p * CQ) * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(y + p * y_cs + c);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
-        v = v * sc + sh;
-        if (residual) v += *reinterpret_cast<const f32x4*>(residual + p * res_cs + c);
-        if (act == ADH_ACT_RELU) {
+    const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t pstep = (int64_t)gridDim.x * 256 / CQ;
+    int64_t p = t / CQ;
+    const int c = (int)(t - p * CQ) * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+    for (; p < P; p += EW_UNROLL * pstep) {
+        f32x4 v[EW_UNROLL], r[EW_UNROLL];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        for (int u = 0; u < EW_UNROLL; ++u) {
+            const int64_t q = p + u * pstep;
+            const bool ok = q < P;
+            v[u] = *reinterpret_cast<const f32x4*>(y + (ok ? q : p) * y_cs + c);
+            if (residual) r[u] = *reinterpret_cast<const f32x4*>(residual + (ok ? q : p) * res_cs + c);
         }
-        *reinterpret_cast<f32x4*>(out + p * out_cs + c) = v;
+#pragma unroll
+        for (int u = 0; u < EW_UNROLL; ++u) {
+            const int64_t q = p + u * pstep;
+            f32x4 w = v[u] * sc + sh;
+            if (residual) w += r[u];
+            if (act == ADH_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = fmaxf(w[j], 0.f);
+            }
+            if (q < P) *reinterpret_cast<f32x4*>(out + q * out_cs + c) = w;
+        }
     }
 }
 
@@ -120,9 +147,8 @@ extern "C" int adh_bn_apply(void* stream, const float* y, int y_cs, const float*
     if (!y || !scale || !shift || !out || P < 1 || C < 4 || (C & 3) || (y_cs & 3) || (out_cs & 3) || (res_cs & 3))
         return ADH_E_ARG;
     const int CQ = C / 4;
-    const int blocks = adh_min_i(adh_ceil_div(P * CQ, 256), 256 * 16);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, y_cs, scale, shift, residual,
-                       res_cs, act, out, out_cs, P, CQ);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(P, CQ)), dim3(256), 0, (hipStream_t)stream, y, y_cs, scale, shift,
+                       residual, res_cs, act, out, out_cs, P, CQ);
     return adh_check_launch();
 }
 
@@ -155,16 +181,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
         const int64_t p0 = (int64_t)blockIdx.x * BNB_PPB;
         const int64_t p1 = p0 + BNB_PPB < P ? p0 + BNB_PPB : P;
-        for (int64_t p = p0 + prow; p < p1; p += R) {
-            f32x4 g = *reinterpret_cast<const f32x4*>(g_out + p * g_cs + c);
-            if (act == ADH_ACT_RELU) {
-                const f32x4 o = *reinterpret_cast<const f32x4*>(out + p * out_cs + c);
+        for (int64_t p = p0 + prow; p < p1; p += 4 * R) {
+            f32x4 g[4], o[4], yy[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t q = p + u * R < p1 ? p + u * R : p;
+                g[u] = *reinterpret_cast<const f32x4*>(g_out + q * g_cs + c);
+                if (act == ADH_ACT_RELU) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
+                yy[u] = *reinterpret_cast<const f32x4*>(y + q * y_cs + c);
             }
-            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + p * y_cs + c);
-            sg += g;
-            sgx += g * ((yy - mu) * is);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p + u * R < p1) {
+                    f32x4 gg = g[u];
+                    if (act == ADH_ACT_RELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gg[j] = o[u][j] > 0.f ? gg[j] : 0.f;
+                    }
+                    sg += gg;
+                    sgx += gg * ((yy[u] - mu) * is);
+                }
+            }
         }
     }
     red[0][threadIdx.x] = sg;
@@ -239,31 +276,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ g_y, int gy_cs, float* __restrict__ g_res,
                                                            int gres_cs, int64_t P, int C) {
     const int CQ = C / 4;
-    const int64_t total = P * CQ;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = idx / CQ;
-        const int c = (int)(idx - p * CQ) * 4;
-        f32x4 g = *reinterpret_cast<const f32x4*>(g_out + p * g_cs + c);
-        if (act == ADH_ACT_RELU) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(out + p * out_cs + c);
+    const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t pstep = (int64_t)gridDim.x * 256 / CQ;
+    int64_t p = t / CQ;
+    const int c = (int)(t - p * CQ) * 4;
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(coef + c);
+    f32x4 mg = {0.f, 0.f, 0.f, 0.f}, kx = mg, mu = mg;
+    if (training) {
+        mg = *reinterpret_cast<const f32x4*>(coef + C + c);
+        const f32x4 mgx = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
+        mu = *reinterpret_cast<const f32x4*>(mean + c);
+        kx = *reinterpret_cast<const f32x4*>(invstd + c) * mgx;
+    }
+    for (; p < P; p += EW_UNROLL * pstep) {
+        f32x4 g[EW_UNROLL], o[EW_UNROLL], yy[EW_UNROLL];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+        for (int u = 0; u < EW_UNROLL; ++u) {
+            const int64_t q = p + u * pstep < P ? p + u * pstep : p;
+            g[u] = *reinterpret_cast<const f32x4*>(g_out + q * g_cs + c);
+            if (act == ADH_ACT_RELU) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
+            if (training) yy[u] = *reinterpret_cast<const f32x4*>(y + q * y_cs + c);
         }
-        if (g_res) *reinterpret_cast<f32x4*>(g_res + p * gres_cs + c) = g;
-        const f32x4 k0 = *reinterpret_cast<const f32x4*>(coef + c);
-        f32x4 r;
-        if (training) {
-            const f32x4 mg = *reinterpret_cast<const f32x4*>(coef + C + c);
-            const f32x4 mgx = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
-            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + p * y_cs + c);
-            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
-            const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
-            r = k0 * (g - mg - (yy - mu) * is * mgx);
-        } else {
-            r = k0 * g;
+#pragma unroll
+        for (int u = 0; u < EW_UNROLL; ++u) {
+            const int64_t q = p + u * pstep;
+            if (q < P) {
+                f32x4 gg = g[u];
+                if (act == ADH_ACT_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gg[j] = o[u][j] > 0.f ? gg[j] : 0.f;
+                }
+                if (g_res) *reinterpret_cast<f32x4*>(g_res + q * gres_cs + c) = gg;
+                f32x4 r;
+                if (training) r = k0 * (gg - mg - (yy[u] - mu) * kx);
+                else r = k0 * gg;
+                *reinterpret_cast<f32x4*>(g_y + q * gy_cs + c) = r;
+            }
         }
-        *reinterpret_cast<f32x4*>(g_y + p * gy_cs + c) = r;
     }
 }
 
@@ -273,8 +322,7 @@ extern "C" int adh_bn_bwd_apply(void* stream, const float* g_out, int g_cs, cons
     if (!g_out || !coef || !g_y || P < 1 || C < 4 || (C & 3)) return ADH_E_ARG;
     if (training && (!y || !mean || !invstd)) return ADH_E_ARG;
     if (act == ADH_ACT_RELU && !out) return ADH_E_ARG;
-    const int blocks = adh_min_i(adh_ceil_div(P * (C / 4), 256), 256 * 16);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_out, g_cs, out, out_cs, act,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P, C / 4)), dim3(256), 0, (hipStream_t)stream, g_out, g_cs, out, out_cs, act,
                        y, y_cs, mean, invstd, coef, training, g_y, gy_cs, g_res, gres_cs, P, C);
     return adh_check_launch();
 }

@@ -96,6 +96,25 @@ def main():
             H.call("adh_bn_apply", y.data_ptr(), Cc, sc.data_ptr(), sh.data_ptr(), None, 0, 1, out.data_ptr(), Cc, P, Cc)
         ms = timeit(bn_apply, args.iters)
         print(f"bn_apply 96ch full  {ms:8.3f} ms  {2 * y.numel() * 4 / ms / 1e9:7.2f} TB/s")
+        g = torch.randn_like(y)
+        mean = torch.zeros(Cc, device=dev)
+        inv = torch.ones(Cc, device=dev)
+        nblk = H.value("adh_bn_bwd_num_blocks", P, Cc)
+        part = torch.empty(nblk, 2, Cc, device=dev)
+        coef = torch.ones(3, Cc, device=dev)
+        gy = torch.empty_like(y)
+
+        def bn_bwd_reduce():
+            H.call("adh_bn_bwd_reduce", g.data_ptr(), Cc, out.data_ptr(), Cc, 1, y.data_ptr(), Cc, mean.data_ptr(),
+                   inv.data_ptr(), part.data_ptr(), P, Cc)
+        ms = timeit(bn_bwd_reduce, args.iters)
+        print(f"bn_bwd_reduce 96ch  {ms:8.3f} ms  {3 * y.numel() * 4 / ms / 1e9:7.2f} TB/s")
+
+        def bn_bwd_apply():
+            H.call("adh_bn_bwd_apply", g.data_ptr(), Cc, out.data_ptr(), Cc, 1, y.data_ptr(), Cc, mean.data_ptr(),
+                   inv.data_ptr(), coef.data_ptr(), 1, gy.data_ptr(), Cc, None, 0, P, Cc)
+        ms = timeit(bn_bwd_apply, args.iters)
+        print(f"bn_bwd_apply 96ch   {ms:8.3f} ms  {4 * y.numel() * 4 / ms / 1e9:7.2f} TB/s")
 
 
 if __name__ == "__main__":
