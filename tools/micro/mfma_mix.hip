@@ -8,7 +8,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-enum { PLAIN, VALU, DS32, DS64, DS128, DSW128, GL128 };
+enum { PLAIN, VALU, DS32, DS64, DS128, DSW128, GL128, DMA128, SALU };
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 template <int KIND, int N, int EVERY>   // N instructions after every EVERY-th MFMA
 __global__ __launch_bounds__(512) void k(float* out, const float* in, int iters) {
@@ -23,6 +24,8 @@ __global__ __launch_bounds__(512) void k(float* out, const float* in, int iters)
     unsigned addr = (threadIdx.x & 255) * 16;   // LDS byte address, 16 B per lane
     float r32; f2v r64; f4v r128; f4v w128 = {1.f, 2.f, 3.f, 4.f};
     const float* gp = in + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + blockIdx.x * 65536, 0, 0x7fffffff, 0x00020000);
+    int sacc = 0;
     for (int it = 0; it < iters; ++it) {
         asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -37,12 +40,14 @@ __global__ __launch_bounds__(512) void k(float* out, const float* in, int iters)
                     if (KIND == DS128) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r128) : "v"(addr), "n"(r * 4096));
                     if (KIND == DSW128) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(w128), "n"(16384 + r * 4096) : "memory");
                     if (KIND == GL128) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r128) : "v"(gp), "n"(r * 256));
+                    if (KIND == DMA128) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(lds + 4096 + (threadIdx.x >> 6) * 256), 16, lane * 16, (it & 63) * 1024, 0, 0);
+                    if (KIND == SALU) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc) : : "scc");
                 }
             }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
-    float s = v0;
+    float s = v0 + sacc;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
     if (KIND == DS32) s += r32;
     if (KIND == DS64) s += r64[0];
@@ -86,6 +91,11 @@ int main() {
         run<GL128, 1, 4>("global_load_x4 x0.25 /mfma", out, in, thr);
         run<GL128, 1, 2>("global_load_x4 x0.5 /mfma", out, in, thr);
         run<GL128, 1, 1>("global_load_x4 x1 /mfma", out, in, thr);
+        run<DMA128, 1, 4>("lds-dma 1KiB x0.25 /mfma", out, in, thr);
+        run<DMA128, 1, 2>("lds-dma 1KiB x0.5 /mfma", out, in, thr);
+        run<DMA128, 1, 1>("lds-dma 1KiB x1 /mfma", out, in, thr);
+        run<SALU, 4, 1>("s_add x4 /mfma", out, in, thr);
+        run<SALU, 12, 1>("s_add x12 /mfma", out, in, thr);
     }
     return 0;
 }
