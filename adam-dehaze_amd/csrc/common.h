@@ -52,3 +52,8 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// conv_rows.hip: direct forward kernel for the 2x2 / 3x3-tap gather forms (0 blocks / ADH_E_UNSUPPORTED when `d`
+// is not one of its shapes; conv_igemm.hip then takes the launch)
+int adh_rows_fwd_num_blocks(const adh_conv_desc* d);
+int adh_rows_fwd_launch(void* stream, const adh_conv_desc* d);

@@ -287,6 +287,8 @@ extern "C" int adh_conv_lds_bytes(const adh_conv_desc* d) {
 }
 
 extern "C" int adh_conv_num_blocks(const adh_conv_desc* d) {
+    const int nb_rows = adh_rows_fwd_num_blocks(d);
+    if (nb_rows > 0) return nb_rows;
     ConvGeom g;
     int TN;
     int rc = conv_plan(d, &g, &TN);
@@ -310,6 +312,8 @@ extern "C" int adh_conv_forward(void* stream, const adh_conv_desc* d) {
     if (((uintptr_t)d->in & 15) || ((uintptr_t)d->wp & 15)) return ADH_E_ARG;
     if ((int64_t)d->IH * d->IW * d->in_cstride >= (1ll << 31) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 31))
         return ADH_E_UNSUPPORTED;
+    rc = adh_rows_fwd_launch(stream, d);
+    if (rc != ADH_E_UNSUPPORTED) return rc;
     const int lds = adh_max_i(g.npxp * g.KC * 4, 4 * 2 * 32 * TN * 4);
     dim3 grid(g.tiles_x * g.tiles_y * d->N, d->NcP / (32 * TN));
     hipStream_t s = (hipStream_t)stream;

@@ -451,6 +451,11 @@ extern "C" int adh_conv_wino_supported(const adh_conv_desc* d) {
     return 1;
 }
 
+extern "C" int adh_conv_wino_num_blocks(const adh_conv_desc* d) {
+    if (!adh_conv_wino_supported(d)) return ADH_E_UNSUPPORTED;
+    return adh_ceil_div(d->OW, 32) * adh_ceil_div(d->OH, 8) * d->N;
+}
+
 template <int NT>
 static int launch_wino(hipStream_t s, const adh_conv_desc* d, WinoGeom g) {
     g.ncog = d->NcP / (32 * NT);

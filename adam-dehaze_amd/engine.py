@@ -296,7 +296,7 @@ class Engine:
                 d.residual = residual.data_ptr()
                 d.res_cstride = residual.stride(2)
             d.act = act
-            nb = H.value("adh_conv_num_blocks", C.byref(d))
+            nb = H.value("adh_conv_wino_num_blocks" if wino else "adh_conv_num_blocks", C.byref(d))
             descs.append((d, nb, wp, wino))
             total_blocks += nb
         stats = None

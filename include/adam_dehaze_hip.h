@@ -96,6 +96,9 @@ int adh_conv_forward(void* stream, const adh_conv_desc* d);
  * adh_conv_wino_supported returns 1 when `d` is eligible (KH=KW=3, unit strides, dy0=dx0=-1, Cin % 16 == 0). */
 int adh_conv_wino_supported(const adh_conv_desc* d);
 int adh_conv_wino_forward(void* stream, const adh_conv_desc* d);
+/* rows of d->stats adh_conv_wino_forward writes (one per 8x32 output region); adh_conv_num_blocks is the count for
+ * adh_conv_forward, whose kernels use other region shapes */
+int adh_conv_wino_num_blocks(const adh_conv_desc* d);
 int adh_pack_weights_wino(void* stream, const float* src, const adh_wlayout* L, float* wp);
 /* weight gradient of the gather form: slab[s][tap][KP][NcP] partial sums over `nsplit` pixel
  * ranges (KP = Cin rounded up to 32); d->out is the gradient wrt the conv output. */

@@ -192,6 +192,9 @@ def _oracle_conv_case(N, Cin, Cout, Hh, Ww, k, stride, pad, seed, transposed=Fal
     (3, 64, 64, 8, 96, 3, 1, 1),       # row-split, TN=2, interior + edge tiles
     (2, 32, 192, 16, 128, 4, 2, 1),    # row-split k4 s2: four kernel-parity sub-launches, TN=3
     (1, 96, 64, 24, 64, 4, 2, 1),      # row-split k4 s2, TN=2
+    (1, 32, 96, 32, 64, 4, 2, 1),      # rows forward kernel: four input-parity classes, Q=3; its dgrad: 2x2 reversed taps
+    (2, 48, 192, 64, 64, 4, 2, 1),     # rows forward kernel, Q=6, image seams
+    (1, 64, 64, 32, 96, 3, 1, 1),      # 3x3 with interior regions (Winograd fwd/dgrad, row-split wgrad)
 ])
 def test_conv_forward_dgrad_wgrad_vs_oracle(N, Cin, Cout, Hh, Ww, k, stride, pad):
     x, w, b = _oracle_conv_case(N, Cin, Cout, Hh, Ww, k, stride, pad, seed=Cin * 1000 + Cout)
@@ -222,7 +225,9 @@ def test_conv_forward_dgrad_wgrad_vs_oracle(N, Cin, Cout, Hh, Ww, k, stride, pad
 
 @pytest.mark.parametrize("N,Cin,Cout,Hh,Ww", [(1, 384, 96, 12, 20), (2, 64, 32, 9, 17), (1, 256, 128, 8, 16),
                                               (2, 64, 96, 8, 64),      # row-split weight gradient (reversed 2x2 taps)
-                                              (1, 32, 64, 12, 32)])
+                                              (1, 32, 64, 12, 32),
+                                              (1, 64, 96, 16, 32),     # rows forward kernel (2x2 taps, strided output)
+                                              (2, 32, 192, 16, 64)])
 def test_conv_transpose_vs_oracle(N, Cin, Cout, Hh, Ww):
     x, w, b = _oracle_conv_case(N, Cin, Cout, Hh, Ww, 4, 2, 1, seed=Cin + Cout, transposed=True)
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
