@@ -13,6 +13,7 @@
 // address offset).  The pixel dimension is split over gridDim.x workgroups; each writes its partial to
 // slab[split] and adh_wgrad_reduce sums the splits in a fixed order (deterministic, no atomics).
 #include "common.h"
+#include <cstdlib>
 
 #define WG_TW 32
 
@@ -242,11 +243,23 @@ __device__ __forceinline__ void wr_mfma_all(f32x16 (&acc)[T * TN], const float (
     }
 }
 
+// Winograd mode: acc[b*TN + j] += V[b] (x) M[j][b] for the wave's four frequencies b and TN n-tiles
+template <int TN, int I>
+__device__ __forceinline__ void wr_mfma_wino(f32x16 (&acc)[4 * TN], const float (&V)[4], const float (&M)[TN][4]) {
+    if constexpr (I < 4 * TN) {
+        wr_mfma<I>(acc[I], V[I / TN], M[I % TN][I / TN]);
+        wr_mfma_wino<TN, I + 1>(acc, V, M);
+    }
+}
+
 // REV: taps walk backwards through the halo (dstep < 0): tap (ty, tx) reads halo offset (KH-1-ty, KW-1-tx)
-template <int KH, int KW, bool REV, int TN>
+// WINO (3x3 taps only): accumulate in the Winograd F(2x2,3x3) domain instead -- see the block comment at the
+// contraction below; wave w then owns frequency row w and the slab holds 16 frequencies instead of 9 taps.
+template <int KH, int KW, bool REV, int TN, bool WINO = false>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_desc d, const WrArgs g, float* slab) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int T = KH * KW;
+    static_assert(!WINO || (KH == 3 && KW == 3 && !REV), "the Winograd weight gradient is a 3x3 form");
+    constexpr int T = WINO ? 4 : KH * KW;          // accumulator tiles per n-tile (frequencies of this wave / taps)
     constexpr int HR = WR_TH + KH - 1;             // halo rows
     constexpr int NC = 32 + KW - 1;                // halo columns in use
     constexpr int NP = HR * 5;                     // DMA pieces of the halo
@@ -376,29 +389,93 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
         if (nty == g.tiles_y) { nty = 0; ++nn; }
         if (tile + 1 < t_end) stage(nn, nty, ntx, cur ^ 1);
 
-        const float* xl = smem + cur * BUF + (wave * WR_HP + h) * 32 + l31;
-        const float* gl = smem + cur * BUF + XF + (wave * 32 + h) * 32 + l31;
-        float a0[T], b0[TN], a1[T], b1[TN];
-        auto ld = [&](const float* xp, const float* gp, float (&av)[T], float (&bv)[TN]) {
+        if constexpr (!WINO) {
+            const float* xl = smem + cur * BUF + (wave * WR_HP + h) * 32 + l31;
+            const float* gl = smem + cur * BUF + XF + (wave * 32 + h) * 32 + l31;
+            float a0[T], b0[TN], a1[T], b1[TN];
+            auto ld = [&](const float* xp, const float* gp, float (&av)[T], float (&bv)[TN]) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int oy = REV ? KH - 1 - t / KW : t / KW, ox = REV ? KW - 1 - t % KW : t % KW;
-                av[t] = xp[(oy * WR_HP + ox) * 32];
-            }
+                for (int t = 0; t < T; ++t) {
+                    const int oy = REV ? KH - 1 - t / KW : t / KW, ox = REV ? KW - 1 - t % KW : t % KW;
+                    av[t] = xp[(oy * WR_HP + ox) * 32];
+                }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = gp[j * 128 * 32];
-        };
-        // software pipeline over the 16 pixel pairs of this wave's row: operands of pair s+1 are in flight while
-        // the T*TN MFMAs of pair s issue (two register sets, pointers bumped once per two pairs)
-        ld(xl, gl, a0, b0);
+                for (int j = 0; j < TN; ++j) bv[j] = gp[j * 128 * 32];
+            };
+            // software pipeline over the 16 pixel pairs of this wave's row: operands of pair s+1 are in flight while
+            // the T*TN MFMAs of pair s issue (two register sets, pointers bumped once per two pairs)
+            ld(xl, gl, a0, b0);
 #pragma unroll 1
-        for (int st = 0; st < 16; st += 2) {
-            ld(xl + 64, gl + 64, a1, b1);
-            wr_mfma_all<T, TN, 0>(acc, a0, b0);
-            xl += 128;
-            gl += 128;
-            if (st + 2 < 16) ld(xl, gl, a0, b0);
-            wr_mfma_all<T, TN, 0>(acc, a1, b1);
+            for (int st = 0; st < 16; st += 2) {
+                ld(xl + 64, gl + 64, a1, b1);
+                wr_mfma_all<T, TN, 0>(acc, a0, b0);
+                xl += 128;
+                gl += 128;
+                if (st + 2 < 16) ld(xl, gl, a0, b0);
+                wr_mfma_all<T, TN, 0>(acc, a1, b1);
+            }
+        } else {
+            // Winograd-domain weight gradient.  With Y = A^T[(G w G^T) . (B^T d B)]A per 2x2 output tile,
+            //   dL/d(G w G^T)[f][ci][co] = sum over tiles of (B^T d B)[f][tile][ci] * (A gy A^T)[f][tile][co],
+            // 16 products of k = tiles instead of 9 of k = pixels: 4/9 of the MFMA work; G^T(.)G is applied once, in
+            // adh_wgrad_reduce_wino.  The 4x32-pixel tile is 2x16 Winograd tiles = 16 MFMA k-steps (lane half h takes
+            // tile column 2s+h).  Wave w owns frequency row a = w.  Both operands are transformed in registers straight
+            // from the raw LDS images in the lane layout the MFMA wants (lane = channel), so nothing is staged twice:
+            //   A side: r[c] = d[rA][c] + sg*d[rB][c] (row a of B^T d; rows and sign are per-wave constants),
+            //           V[b] = r0-r2, r1+r2, r2-r1, r1-r3                                         (8 VALU)
+            //   B side: t[j] = gy[rP][j] + be*gy[1][j] (row a of A gy; rP = 1 and be = 0 for a = 3),
+            //           M[b] = t0, t0+t1, t0-t1, t1                                    (4 VALU per n-tile)
+            // The two minus signs of A's last row / column (a = 3: -gy1, b = 3: -t1) are left out here and applied by the
+            // reduce kernel (dU[a][b] *= s_a s_b, s_3 = -1).
+            const int rA = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+            const int rB = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+            const float sg = wave == 1 ? 1.f : -1.f;
+            const int rP = wave == 3 ? 1 : 0;
+            const float be = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+            const float* xa = smem + cur * BUF + (rA * WR_HP + 2 * h) * 32 + l31;
+            const float* xb = smem + cur * BUF + (rB * WR_HP + 2 * h) * 32 + l31;
+            const float* gp = smem + cur * BUF + XF + (rP * 32 + 2 * h) * 32 + l31;
+            const float* gq = smem + cur * BUF + XF + (32 + 2 * h) * 32 + l31;
+            float ra[2][4], rb[2][4], gr[2][TN][4];
+            auto ld = [&](int tr, int sp, float (&va)[4], float (&vb)[4], float (&vg)[TN][4]) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    va[c] = xa[((2 * tr) * WR_HP + 4 * sp + c) * 32];
+                    vb[c] = xb[((2 * tr) * WR_HP + 4 * sp + c) * 32];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)   // e = 2*i + jj: row pointer (gp, gq), output column jj of the tile
+                        vg[j][e] = ((e >> 1) ? gq : gp)[(j * 128 + (2 * tr) * 32 + 4 * sp + (e & 1)) * 32];
+            };
+            ld(0, 0, ra[0], rb[0], gr[0]);
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                if (st + 1 < 16) ld((st + 1) >> 3, (st + 1) & 7, ra[(st + 1) & 1], rb[(st + 1) & 1], gr[(st + 1) & 1]);
+                const float(&va)[4] = ra[st & 1];
+                const float(&vb)[4] = rb[st & 1];
+                float r[4], V[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r[c] = fmaf(sg, vb[c], va[c]);
+                V[0] = r[0] - r[2];
+                V[1] = r[1] + r[2];
+                V[2] = r[2] - r[1];
+                V[3] = r[1] - r[3];
+                float M[TN][4];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float(&vg)[4] = gr[st & 1][j];
+                    const float t0 = fmaf(be, vg[2], vg[0]);
+                    const float t1 = fmaf(be, vg[3], vg[1]);
+                    M[j][0] = t0;
+                    M[j][1] = t0 + t1;
+                    M[j][2] = t0 - t1;
+                    M[j][3] = t1;
+                }
+                wr_mfma_wino<TN, 0>(acc, V, M);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -406,19 +483,35 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
         tx = ntx; ty = nty; n = nn;
     }
 
-    // partial result -> slab[4*split + wave][tap][KP][NcP]
     const int KP = d.Cin;
-    float* sbase = slab + ((size_t)(split * 4 + wave) * g.Ttot) * KP * d.NcP;
+    if constexpr (WINO) {
+        // partial result -> slab[split][f = 4*wave + b][KP][NcP]
+        float* sbase = slab + ((size_t)split * 16 + wave * 4) * KP * d.NcP;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int tap = g.tap0 + (t / KW) * g.tap_sy + (t % KW) * g.tap_sx;
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float* base = sbase + ((size_t)tap * KP + ci0) * d.NcP + co0 + 32 * j + l31;
+            for (int j = 0; j < TN; ++j) {
+                float* base = sbase + ((size_t)b * KP + ci0) * d.NcP + co0 + 32 * j + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                base[(size_t)i * d.NcP] = acc[t * TN + j][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    base[(size_t)i * d.NcP] = acc[b * TN + j][r];
+                }
+            }
+    } else {
+        // partial result -> slab[4*split + wave][tap][KP][NcP]
+        float* sbase = slab + ((size_t)(split * 4 + wave) * g.Ttot) * KP * d.NcP;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int tap = g.tap0 + (t / KW) * g.tap_sy + (t % KW) * g.tap_sx;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float* base = sbase + ((size_t)tap * KP + ci0) * d.NcP + co0 + 32 * j + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    base[(size_t)i * d.NcP] = acc[t * TN + j][r];
+                }
             }
         }
     }
@@ -549,6 +642,133 @@ static int dispatch_wgrad_rows(hipStream_t s, const adh_conv_desc* d, const WrPl
 
 static bool wgrad_rows_instantiated(const WrPlan& p) {
     return (p.KH == 3 && p.KW == 3 && !p.rev) || (p.KH == 2 && p.KW == 2);
+}
+
+// ---- Winograd-domain weight gradient of 3x3 unit-stride convolutions (conv_wgrad_rows_kernel<3,3,0,TN,true>) ----
+static int wgrad_wino_plan(const adh_conv_desc* d, int nsplit, WrPlan* p) {
+    static const bool enabled = !(getenv("ADH_WINO_WGRAD") && atoi(getenv("ADH_WINO_WGRAD")) == 0);   // A/B switch
+    if (!enabled) return 0;
+    WrPlan plan[4];
+    if (wgrad_rows_plan(d, nsplit, plan) != 1) return 0;
+    if (plan[0].KH != 3 || plan[0].KW != 3 || plan[0].rev || plan[0].a.xps != 1) return 0;
+    if (d->dy0 != -1 || d->dx0 != -1) return 0;
+    *p = plan[0];
+    return 1;
+}
+
+extern "C" int adh_conv_wgrad_wino_groups(const adh_conv_desc* d) {
+    if (!d) return ADH_E_ARG;
+    WrPlan p;
+    return wgrad_wino_plan(d, 1, &p) ? p.a.ngroups : 0;
+}
+
+extern "C" int adh_conv_wgrad_wino(void* stream, const adh_conv_desc* d, float* slab, int nsplit) {
+    if (!d || !slab || nsplit < 1 || !d->in || !d->out) return ADH_E_ARG;
+    WrPlan p;
+    if (!wgrad_wino_plan(d, nsplit, &p)) return ADH_E_UNSUPPORTED;
+    const int lds = 2 * (((WR_TH + 2) * WR_HP + p.TN * WR_TH * 32) * 32 * 4);
+    const int nblocks = ((nsplit + 7) / 8) * p.a.ngroups * 8;
+    hipStream_t s = (hipStream_t)stream;
+#define WW_CASE(tn_) \
+    if (p.TN == tn_) { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_kernel<3, 3, false, tn_, true>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((conv_wgrad_rows_kernel<3, 3, false, tn_, true>), dim3(nblocks), dim3(256), lds, s, *d, p.a, slab); \
+        return adh_check_launch(); \
+    }
+    WW_CASE(3) WW_CASE(2) WW_CASE(1)
+#undef WW_CASE
+    return ADH_E_UNSUPPORTED;
+}
+
+// dst(layout L, 3x3) (+)= G^T (sum over splits of slab[s][16][KP][NcP], with the two deferred signs) G
+__global__ void wgrad_reduce_wino_kernel(const float* __restrict__ slab, int nsplit, int KP, int NcP, const adh_wlayout L,
+                                         float* __restrict__ dst, int accumulate) {
+    const int64_t total = (int64_t)L.K * L.Nc;
+    const int64_t fstride = (int64_t)KP * NcP, split_stride = 16 * fstride;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % L.Nc);
+        const int k = (int)(idx / L.Nc);
+        const float* p = slab + (int64_t)k * NcP + n;
+        // 16 frequencies x nsplit partial sums: keep 32-64 independent loads in flight (the inner loops are over
+        // frequencies, the splits advance two at a time) -- with few (k, n) pairs this kernel is latency-bound
+        float ua[16], ub[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) ua[f] = ub[f] = 0.f;
+        int sp = 0;
+        for (; sp + 2 <= nsplit; sp += 2) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                ua[f] += p[(int64_t)sp * split_stride + f * fstride];
+                ub[f] += p[(int64_t)(sp + 1) * split_stride + f * fstride];
+            }
+        }
+        if (sp < nsplit) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) ua[f] += p[(int64_t)sp * split_stride + f * fstride];
+        }
+        float u[4][4];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            const float sign = ((f >> 2) == 3) != ((f & 3) == 3) ? -1.f : 1.f;
+            u[f >> 2][f & 3] = sign * (ua[f] + ub[f]);
+        }
+        // G^T u G with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+        float t[3][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+            t[1][b] = 0.5f * (u[1][b] - u[2][b]);
+            t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float w[3];
+            w[0] = t[i][0] + 0.5f * (t[i][1] + t[i][2]);
+            w[1] = 0.5f * (t[i][1] - t[i][2]);
+            w[2] = 0.5f * (t[i][1] + t[i][2]) + t[i][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int64_t off = (int64_t)L.tap_off0 + i * L.tap_off_sy + j * L.tap_off_sx + (int64_t)k * L.stride_k +
+                                    (int64_t)n * L.stride_n;
+                dst[off] = accumulate ? dst[off] + w[j] : w[j];
+            }
+        }
+    }
+}
+
+// slab[0] = sum over splits (fixed order), 16 bytes per lane, eight independent loads in flight
+__global__ __launch_bounds__(256) void wgrad_sum_splits_kernel(float* __restrict__ slab, int nsplit, int64_t n4) {
+    f32x4* s4 = reinterpret_cast<f32x4*>(slab);
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += s4[(int64_t)(sp + u) * n4 + i];
+        }
+        for (; sp < nsplit; ++sp) a[0] += s4[(int64_t)sp * n4 + i];
+        s4[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+}
+
+extern "C" int adh_wgrad_reduce_wino(void* stream, float* slab, int nsplit, int KP, int NcP, const adh_wlayout* L,
+                                     float* dst, int accumulate) {
+    if (!slab || !L || !dst || nsplit < 1 || L->KHt != 3 || L->KWt != 3 || (NcP & 3)) return ADH_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (nsplit > 1) {
+        // many splits x few (k, n) pairs would leave the transform kernel latency-bound: stream-sum the splits first
+        const int64_t n4 = (int64_t)16 * KP * NcP / 4;
+        hipLaunchKernelGGL(wgrad_sum_splits_kernel, dim3(adh_min_i(adh_ceil_div(n4, 256), 2048)), dim3(256), 0, s, slab,
+                           nsplit, n4);
+    }
+    const int64_t total = (int64_t)L->K * L->Nc;
+    hipLaunchKernelGGL(wgrad_reduce_wino_kernel, dim3(adh_min_i(adh_ceil_div(total, 64), 16384)), dim3(64), 0, s, slab, 1,
+                       KP, NcP, *L, dst, accumulate);
+    return adh_check_launch();
 }
 
 extern "C" int adh_conv_wgrad_groups(const adh_conv_desc* d) {

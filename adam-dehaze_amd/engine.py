@@ -341,6 +341,18 @@ class Engine:
             zgroups = 7 if T_all == 49 else 1
             groups = (KP // 32) * max(1, NcP // 96) * zgroups
             # one 512-thread workgroup per CU is resident: aim at ~4 rounds of 256 workgroups
+            T = gm["KH"] * gm["KW"]
+            wino_groups = H.value("adh_conv_wgrad_wino_groups", C.byref(d)) if USE_WINOGRAD else 0
+            if wino_groups:
+                # 3x3 stride-1: accumulate in the Winograd domain (16 frequency slabs), G^T(.)G in the reduce
+                nsplit = _rows_nsplit(wino_groups, ntiles_est)
+                while nsplit * 16 * KP * NcP * 4 > (1 << 30) and nsplit > 1:
+                    nsplit //= 2
+                slab = self._f(nsplit * 16 * KP * NcP)
+                H.call("adh_conv_wgrad_wino", C.byref(d), slab.data_ptr(), nsplit,
+                       work=2.0 * d.N * d.VH * d.VW * T * L.K * L.Nc, work_exec=2.0 * d.N * d.VH * d.VW * 4 * L.K * L.Nc)
+                H.call("adh_wgrad_reduce_wino", slab.data_ptr(), nsplit, KP, NcP, C.byref(L), dw.data_ptr(), 0)
+                continue
             nsplit = max(1, min(ntiles_est, max(1, 1024 // groups), 512))
             rows_groups = H.value("adh_conv_wgrad_groups", C.byref(d))
             if rows_groups:

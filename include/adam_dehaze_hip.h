@@ -113,6 +113,15 @@ int adh_conv_wgrad_groups(const adh_conv_desc* d);
 int adh_wgrad_reduce(void* stream, const float* slab, int nsplit, int KP, int NcP,
                      const adh_wlayout* L, float* dst, int accumulate);
 
+/* Winograd-domain weight gradient of Conv2d k3 s1 p1 (VW % 32 == 0, VH % 4 == 0, Cin % 32 == 0, Cout % 32 == 0):
+ * slab[s][16][KP][NcP] holds d/d(G w G^T) per frequency at 4/9 of the direct MFMA work; adh_wgrad_reduce_wino sums
+ * the splits and applies G^T(.)G into the 3x3 layout L.  adh_conv_wgrad_wino_groups: workgroups per pixel split
+ * (0 = descriptor not eligible, use adh_conv_wgrad). */
+int adh_conv_wgrad_wino_groups(const adh_conv_desc* d);
+int adh_conv_wgrad_wino(void* stream, const adh_conv_desc* d, float* slab, int nsplit);
+int adh_wgrad_reduce_wino(void* stream, float* slab /* scratch: split 0 receives the sum */, int nsplit, int KP, int NcP,
+                          const adh_wlayout* L, float* dst, int accumulate);
+
 /* Packed small-Cin weight gradient (7x7 stems, Cin <= 8 stored with cstride 8): call adh_conv_wgrad with
  * KW = ceil(kw/4), dstep_x = 4, Cin = 8 -- the 32-wide MFMA row tile then spans 4 adjacent pixels x 8
  * channels -- and unpack slab[s][ky*KWg + kxg][kxl*8 + ci][NcP] into OIHW with this call. */

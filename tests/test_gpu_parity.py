@@ -335,3 +335,24 @@ def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, monkeypatch):
     assert max_abs(got[True][2], got[False][2]) < 4e-6 * scale
     ref_s = got[False][1]
     assert float((got[True][1] - ref_s).abs().max()) < 2e-5 * float(ref_s.abs().max())
+
+@pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 96, 96, 12, 64), (1, 32, 64, 24, 96), (3, 64, 32, 8, 32), (1, 192, 96, 16, 64)])
+def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, monkeypatch):
+    """conv_wgrad_rows_kernel in Winograd mode + adh_wgrad_reduce_wino against the direct row-split kernel and the
+    fp64 definition, on tiles with and without image borders."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(Ci + 7 * Hh)
+    x = torch.randn(N, Hh, Ww, Ci, generator=g)
+    gy = torch.randn(N, Hh, Ww, Co, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3, device=DEV, requires_grad=True)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Co, Ci, 3, 3), gy.permute(0, 3, 1, 2).double(),
+                                      stride=1, padding=1)
+    got = {}
+    for wino in (False, True):
+        monkeypatch.setattr(E, "USE_WINOGRAD", wino)
+        eng = Engine(torch.device(DEV), record=False)
+        plans = eng._launch_plan("conv", 3, 1, 1, w, "fwd")
+        got[wino] = eng._wgrad(plans, Act(x.to(DEV)), gy.to(DEV), Co, w).cpu().double()
+    scale = float(ref.abs().max())
+    assert float((got[False] - ref).abs().max()) < 2e-5 * scale
+    assert float((got[True] - ref).abs().max()) < 2e-5 * scale
