@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
     const int xv = (lane >> 3) * xcs + (lane & 7) * 16;    // per-lane byte offsets inside one 8-pixel piece
     const int gv = (lane >> 3) * gcs + (lane & 7) * 16;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool g_partial = co0 + 32 * TN > d.Cout;   // this group's last n-tile has channels beyond Cout
 
     // this wave's halo pieces: piece j = wave + 4u covers halo row j/5, pixels 8*(j%5) .. +7 (wave-uniform scalars)
     int prow[8], pcb[8], poff[8], pdst[8];   // PU <= 8 (sized literally: a dependent bound breaks hipcc's host pass)
@@ -357,16 +358,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
                 }
             }
         }
-        // G: wave w stages pixel row w: TN x 4 pieces (always inside the tensor)
+        // G: wave w stages pixel row w: TN x 4 pieces (pixels always inside the tensor; the channel quads of a partial
+        // last n-tile -- Cout % 32 != 0 -- are lane-masked: their LDS cells keep the zeros written at kernel start)
         const int sg = (ty * WR_TH + wave) * grs + tx * 32 * gcs;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 float* dst = gs + (tn * 128 + wave * 32 + cb * 8) * 32;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void_ptr)dst, 16, gv, sg + cb * 8 * gcs + tn * 128, 0, 0);
+                if (!g_partial || co0 + tn * 32 + (lane & 7) * 4 < d.Cout)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void_ptr)dst, 16, gv, sg + cb * 8 * gcs + tn * 128, 0, 0);
             }
     };
+    if (g_partial) {
+        for (int i = tid; i < 2 * BUF / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = zero4;
+        __syncthreads();
+    }
 
     f32x16 acc[T * TN];
 #pragma unroll
@@ -572,21 +579,21 @@ struct WrPlan {
 
 static int wgrad_rows_plan(const adh_conv_desc* d, int nsplit, WrPlan plan[4]) {
     if (d->VW % 32 != 0 || d->VH % WR_TH != 0) return 0;
-    if (d->Cin % 32 != 0 || d->Cout % 32 != 0 || d->NcP != d->Cout) return 0;
+    if (d->Cin % 32 != 0 || d->Cout % 4 != 0 || d->NcP != adh_round_up(d->Cout, 32)) return 0;
     if (d->in_cstride % 4 != 0 || d->out_cstride % 4 != 0) return 0;
     if (d->in_sy != d->in_sx || d->dstep_y != d->dstep_x || d->out_sy != d->out_sx) return 0;
     if ((d->VH - 1) * d->out_sy + d->out_oy >= d->OH || (d->VW - 1) * d->out_sx + d->out_ox >= d->OW) return 0;
     // 32-bit byte offsets inside one image (the descriptors are per image)
     if ((int64_t)(d->IH + 8) * d->IW * d->in_cstride * 4 >= (int64_t)1 << 31) return 0;
     if ((int64_t)d->OH * d->OW * d->out_cstride * 4 >= (int64_t)1 << 31) return 0;
-    const int t = d->Cout / 32;
+    const int t = d->NcP / 32;
     const int TN = t % 3 == 0 ? 3 : (t % 2 == 0 ? 2 : 1);
     WrArgs base;
     base.tiles_x = d->VW / 32;
     base.tiles_y = d->VH / WR_TH;
     base.ntiles = base.tiles_x * base.tiles_y * d->N;
     base.nsplit = nsplit;
-    base.nco_groups = d->Cout / (32 * TN);
+    base.nco_groups = d->NcP / (32 * TN);
     base.ngroups = (d->Cin / 32) * base.nco_groups;
     base.Ttot = d->KH * d->KW;
     const int s = d->in_sy, ds = d->dstep_y;

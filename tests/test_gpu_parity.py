@@ -336,7 +336,9 @@ def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, monkeypatch):
     ref_s = got[False][1]
     assert float((got[True][1] - ref_s).abs().max()) < 2e-5 * float(ref_s.abs().max())
 
-@pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 96, 96, 12, 64), (1, 32, 64, 24, 96), (3, 64, 32, 8, 32), (1, 192, 96, 16, 64)])
+@pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 96, 96, 12, 64), (1, 32, 64, 24, 96), (3, 64, 32, 8, 32), (1, 192, 96, 16, 64),
+                                           (2, 96, 48, 16, 64),     # partial last n-tile (output_conv.1 of the headline model)
+                                           (1, 32, 16, 8, 32)])
 def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, monkeypatch):
     """conv_wgrad_rows_kernel in Winograd mode + adh_wgrad_reduce_wino against the direct row-split kernel and the
     fp64 definition, on tiles with and without image borders."""
