@@ -488,6 +488,462 @@ extern "C" int adh_conv_wino_forward(void* stream, const adh_conv_desc* d) {
     return launch_wino<1>(s, d, g);
 }
 
+// =====================================================================================================================
+// Winograd F(3x3, 2x2): the 2x2-tap gather forms (each output-parity class of ConvTranspose2d k4 s2, Conv2d k4 s2 as four
+// input-parity classes, and their data gradients) at 4/9 of the direct MFMA work.
+//
+//   Y(3x3) = G^T [ (A g A^T) .* (B^T d B) ] G        d: 4x4 input patch, g: 2x2 filter
+//
+// is the F(2x2,3x3) algorithm with the roles of filter and output exchanged (same trilinear form): the input transform
+// B^T d B is the one above, the weights are packed as U = A g A^T (adh_pack_weights_wino32) and the output transform is
+// G^T M G.  Same kernel skeleton as conv_wino_kernel (4 waves, wave = frequency row, AGPR-pinned accumulators, LDS-DMA
+// raw staging, asm weight prefetch with counted waits); what differs:
+//   * region = 4 x 16 tiles of 3x3 = 12 x 48 virtual pixels, tiles step by 3: the raw halo 13 x 49 pixels is laid out
+//     [row][column mod 3][16 px][16 ch] (+ column 48 of every row in a tail), 40 DMA pieces per slab, 10 per wave; edge
+//     regions load from clamped coordinates (every instruction issues with all lanes) and zero the cells afterwards;
+//   * the raw tile is double buffered and V single buffered (the larger halo does not leave room for two V buffers):
+//     a slab is contracted, then the next one is transformed -- VALU and MFMA work do not overlap anyway;
+//   * the K loop runs over slabs = (16 input channels, input-parity class); a class only changes scalar offsets;
+//   * outputs are written with the descriptor's output stride / offset (parity classes of a transposed convolution).
+#define W3_RAW_PITCH 768                             // floats per raw row: [3 planes][16 px][16 ch]
+#define W3_RAW_ROWS 13
+#define W3_RAW_F (W3_RAW_ROWS * W3_RAW_PITCH + 256)  // + tail [16 slots][16 ch]: column 48 of rows 0..12
+#define W3_LDS_BYTES ((W2_VBUF_F + 2 * W3_RAW_F + 2 * 8 * 32) * 4)
+
+struct Wino32Geom {
+    int tiles_x, tiles_y;        // 48-col x 12-row regions of virtual pixels
+    int nregions;
+    int nchunks;                 // Cin / 16
+    int KQtot;                   // Cin / 4
+    int ncog;
+    int ncls, xps;               // input-parity classes (1 or 4), input pixels per virtual pixel
+    int ymin[4], xmin[4];        // input pixel of halo (0,0) for virtual pixel (0,0), per class
+    int wcls;                    // floats between the packed weights of two classes
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc d, const Wino32Geom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // V[16][64][16] | raw[2][13][768]+tail | red
+    float* const rawbase = lds + W2_VBUF_F;
+    float* const red = rawbase + 2 * W3_RAW_F;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int q = bid >> 3;
+    const int cg = q % g.ncog;
+    const int region = (q / g.ncog) * 8 + (bid & 7);
+    if (region >= g.nregions) return;
+    int rr = region;
+    const int tx = rr % g.tiles_x;
+    rr /= g.tiles_x;
+    const int ty = rr % g.tiles_y;
+    const int n = rr / g.tiles_y;
+    const int vy0 = ty * 12, vx0 = tx * 48;
+    const int co0 = cg * 32 * NT;
+
+    // ------------------------------------------------------------------ raw halo staging (LDS-DMA), 10 pieces per wave
+    const int xcs = d.in_cstride * 4 * g.xps;                  // halo pixel pitch in bytes
+    const int xrs = d.IW * d.in_cstride * 4 * g.xps;           // halo row pitch in bytes
+    const float* const in_n = d.in + (int64_t)n * d.IH * d.IW * d.in_cstride;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, 0x7fffffff, 0x00020000);
+    const int cq_l = lane & 3, px_l = lane >> 2;
+    // all classes' halo columns are inside the image: no clamping / fixing needed (rows are checked per piece)
+    auto stage_raw = [&](int slab, int buf) {
+        const int chunk = slab / g.ncls, c = slab - chunk * g.ncls;
+        const int iy0 = vy0 * g.xps + g.ymin[c], ix0 = vx0 * g.xps + g.xmin[c];
+        float* raw = rawbase + buf * W3_RAW_F;
+        const bool interior = iy0 >= 0 && iy0 + 12 * g.xps < d.IH && ix0 >= 0 && ix0 + 48 * g.xps < d.IW;
+        const int cb = chunk * 64;
+        if (interior) {
+            const int so0 = (iy0 * d.IW + ix0) * d.in_cstride * 4 + cb;
+            const int vfull = 3 * px_l * xcs + cq_l * 16;
+            const int vtail = (px_l < W3_RAW_ROWS ? px_l : 0) * xrs + 48 * xcs + cq_l * 16;
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int j = 4 * u + wave;
+                if (j < 39) {
+                    const int r = (j * 171) >> 9, p = j - r * 3;       // j / 3
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + r * W3_RAW_PITCH + p * 256), 16, vfull,
+                                                             __builtin_amdgcn_readfirstlane(so0 + r * xrs + p * xcs), 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + W3_RAW_ROWS * W3_RAW_PITCH), 16, vtail,
+                                                             __builtin_amdgcn_readfirstlane(so0), 0, 0);
+                }
+            }
+        } else {
+            // clamped per-lane coordinates: every instruction issues with all lanes; fix_raw zeroes the cells that lie
+            // outside the image after they have landed
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int j = 4 * u + wave;
+                const bool tail = j >= 39;
+                const int rs = (j * 171) >> 9, p = tail ? 0 : j - rs * 3;      // full pieces: row, plane (wave-uniform)
+                const int r = tail ? (px_l < W3_RAW_ROWS ? px_l : 0) : rs;
+                const int col = tail ? 48 : 3 * px_l + p;
+                const int iy = adh_min_i(adh_max_i(iy0 + r * g.xps, 0), d.IH - 1);
+                const int ix = adh_min_i(adh_max_i(ix0 + col * g.xps, 0), d.IW - 1);
+                const int vo = (iy * d.IW + ix) * d.in_cstride * 4 + cq_l * 16;
+                const int doff = __builtin_amdgcn_readfirstlane(tail ? W3_RAW_ROWS * W3_RAW_PITCH : rs * W3_RAW_PITCH + p * 256);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + doff), 16, vo, __builtin_amdgcn_readfirstlane(cb), 0, 0);
+            }
+        }
+    };
+    auto fix_raw = [&](int slab, int buf) {
+        const int chunk = slab / g.ncls, c = slab - chunk * g.ncls;
+        const int iy0 = vy0 * g.xps + g.ymin[c], ix0 = vx0 * g.xps + g.xmin[c];
+        if (iy0 >= 0 && iy0 + 12 * g.xps < d.IH && ix0 >= 0 && ix0 + 48 * g.xps < d.IW) return;
+        float* raw = rawbase + buf * W3_RAW_F;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int j = 4 * u + wave;
+            const bool tail = j >= 39;
+            const int r = tail ? px_l : ((j * 171) >> 9);
+            const int p = tail ? 0 : j - ((j * 171) >> 9) * 3;
+            const int col = tail ? 48 : 3 * px_l + p;
+            const int iy = iy0 + r * g.xps, ix = ix0 + col * g.xps;
+            const bool ok = iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
+            float* dst = (tail ? raw + W3_RAW_ROWS * W3_RAW_PITCH : raw + r * W3_RAW_PITCH + p * 256) + lane * 4;
+            if (!ok && (!tail || px_l < W3_RAW_ROWS)) *reinterpret_cast<f32x4*>(dst) = z;
+        }
+    };
+
+    // ------------------------------------------------------------------ input transform: thread = (tile, channel quad)
+    const int tcol = lane >> 2;          // tile row = wave
+    const int tile_t = wave * 16 + tcol;
+    int colb[3], colb3[4];               // float offsets of patch columns 0..2 (row pitch immediate) and of column 3 per row
+#pragma unroll
+    for (int b = 0; b < 3; ++b) colb[b] = (3 * wave) * W3_RAW_PITCH + b * 256 + tcol * 16 + cq_l * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        colb3[i] = (tcol < 15 ? (3 * wave + i) * W3_RAW_PITCH + (tcol + 1) * 16 : W3_RAW_ROWS * W3_RAW_PITCH + (3 * wave + i) * 16) + cq_l * 4;
+    const int vslot_t = tile_t * 16 + ((cq_l ^ ((tile_t >> 1) & 3)) * 4);
+    auto transform = [&](int buf) {
+        // frequency row by frequency row (row a of B^T d needs two patch rows): 8 patch reads per row instead of 16 in
+        // total, but only ~50 live registers -- this kernel has none to spare next to 8*NT accumulator tiles
+        const float* raw = rawbase + buf * W3_RAW_F;
+        float* Vb = lds + vslot_t;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int rA = a == 0 ? 0 : (a == 2 ? 2 : 1), rB = a == 0 ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 3));
+            f32x4 t[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f32x4 dA = *reinterpret_cast<const f32x4*>(b < 3 ? raw + colb[b] + rA * W3_RAW_PITCH : raw + colb3[rA]);
+                const f32x4 dB = *reinterpret_cast<const f32x4*>(b < 3 ? raw + colb[b] + rB * W3_RAW_PITCH : raw + colb3[rB]);
+                t[b] = a == 1 ? dA + dB : dA - dB;
+            }
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 0) * 1024) = t[0] - t[2];
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 1) * 1024) = t[1] + t[2];
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 2) * 1024) = t[2] - t[1];
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 3) * 1024) = t[1] - t[3];
+        }
+    };
+
+    // ------------------------------------------------------------------ contraction operands (as conv_wino_kernel)
+    const int sw = (l31 >> 1) & 3;
+    const int a_lane = (wave * 4) * 1024 + l31 * 16 + ((h ^ sw) * 4);
+    const unsigned b_voff = (unsigned)((h * d.NcP + l31) * 16);
+    const float* const b_wave = d.wp + ((int64_t)(wave * 4) * g.KQtot * d.NcP + co0) * 4;
+    const int64_t b_fstride = (int64_t)g.KQtot * d.NcP * 4;
+    const int b_kqstride = d.NcP * 4;
+
+    f32x16 acc[8 * NT];
+#pragma unroll
+    for (int t = 0; t < 8 * NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    f32x4 av[2][2], bv[2][NT];
+    auto load_a = [&](int f, int gg, f32x4 (&a)[2]) {
+        const float* p = lds + f * 1024 + (gg ? (a_lane ^ 8) : a_lane);
+        a[0] = *reinterpret_cast<const f32x4*>(p);
+        a[1] = *reinterpret_cast<const f32x4*>(p + 512);
+    };
+    auto b_ptr = [&](int slab, int f, int gg) {
+        const int chunk = slab / g.ncls, c = slab - chunk * g.ncls;
+        return b_wave + (int64_t)c * g.wcls + f * b_fstride + (int64_t)(chunk * 4 + 2 * gg) * b_kqstride;
+    };
+
+    // ------------------------------------------------------------------ prologue
+    const int nslabs = g.nchunks * g.ncls;
+    w2_load_b<NT>(bv[0], b_voff, b_ptr(0, 0, 0));
+    stage_raw(0, 0);
+    stage_raw(nslabs > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fix_raw(0, 0);
+    fix_raw(nslabs > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    transform(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll 1
+    for (int s = 0; s < nslabs; ++s) {
+        // raw(s+1) sits in buffer (s+1)&1 (landed and fixed); raw(s+2) goes into buffer s&1, free since transform(s)
+        const int s2 = s + 2 < nslabs ? s + 2 : s;     // the last two slabs re-issue an earlier tile: uniform counts
+        const int sn = s + 1 < nslabs ? s + 1 : s;
+        load_a(0, 0, av[0]);
+        w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 1, 0));
+        stage_raw(s2, s & 1);
+        load_a(1, 0, av[1]);
+        w2_wait_b<NT + 10, NT>(bv[0]);
+        w2_group<NT, 0, 0, 0, 0>(acc, av[0], bv[0]);
+
+        w2_load_b<NT>(bv[0], b_voff, b_ptr(s, 2, 0));
+        load_a(2, 0, av[0]);
+        w2_wait_b<NT + 10, NT>(bv[1]);
+        w2_group<NT, 1, 0, 0, 0>(acc, av[1], bv[1]);
+
+        w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 3, 0));
+        load_a(3, 0, av[1]);
+        w2_wait_b<NT, NT>(bv[0]);            // also retires this wave's 10 raw pieces (in-order return)
+        w2_group<NT, 2, 0, 0, 0>(acc, av[0], bv[0]);
+
+        w2_load_b<NT>(bv[0], b_voff, b_ptr(s, 0, 1));
+        load_a(0, 1, av[0]);
+        w2_wait_b<NT, NT>(bv[1]);
+        w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
+
+        w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 1, 1));
+        load_a(1, 1, av[1]);
+        w2_wait_b<NT, NT>(bv[0]);
+        w2_group<NT, 0, 0, 0, 0>(acc, av[0], bv[0]);
+
+        w2_load_b<NT>(bv[0], b_voff, b_ptr(s, 2, 1));
+        load_a(2, 1, av[0]);
+        w2_wait_b<NT, NT>(bv[1]);
+        w2_group<NT, 1, 0, 0, 0>(acc, av[1], bv[1]);
+
+        w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 3, 1));
+        load_a(3, 1, av[1]);
+        w2_wait_b<NT, NT>(bv[0]);
+        w2_group<NT, 2, 0, 0, 0>(acc, av[0], bv[0]);
+
+        w2_load_b<NT>(bv[0], b_voff, b_ptr(sn, 0, 0));
+        w2_wait_b<NT, NT>(bv[1]);
+        w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
+        // ---- V is free once every wave is here; the tile staged during this slab has landed (third wait above)
+        fix_raw(s2, s & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        transform((s + 1) & 1);              // (after the last slab: a harmless re-transform, keeps the span branch-free)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    w2_wait_b<0, NT>(bv[0]);
+
+    // ---------------------------------------------------------------------- output transform G^T M G + fused epilogue
+    float* M = lds;   // [16][64][32]: spans V and the raw buffers
+    const int cl = tid & 31;
+    float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
+    const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        __builtin_amdgcn_s_barrier();   // V / raw (first tile) or the previous tile's M fully consumed
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = (r & 3) + 8 * (r >> 2) + 4 * h + 32 * th;
+                    M[((wave * 4 + f) * W2_TILES + t) * 32 + l31] = acc[(f * 2 + th) * NT + j][r];
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int co = co0 + j * 32 + cl;
+        const bool cvalid = co < d.Cout;
+        const float sc = (d.scale && cvalid) ? d.scale[co] : 1.f;
+        const float sh = (d.shift && cvalid) ? d.shift[co] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll 1
+        for (int p = 0; p < 8; ++p) {
+            const int t = (tid >> 5) + 8 * p;
+            const int trow = t >> 4, tc = t & 15;
+            float m[16];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) m[f] = M[(f * W2_TILES + t) * 32 + cl];
+            // G^T M: rows 0..2 from frequency rows 0..3
+            float u[3][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float hs = 0.5f * (m[1 * 4 + b] + m[2 * 4 + b]), hd = 0.5f * (m[1 * 4 + b] - m[2 * 4 + b]);
+                u[0][b] = m[0 * 4 + b] + hs;
+                u[1][b] = hd;
+                u[2][b] = hs + m[3 * 4 + b];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float hs = 0.5f * (u[i][1] + u[i][2]), hd = 0.5f * (u[i][1] - u[i][2]);
+                const float y[3] = {u[i][0] + hs, hd, hs + u[i][3]};
+                const int vy = vy0 + 3 * trow + i;
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    const int vx = vx0 + 3 * tc + jj;
+                    if (cvalid && vy < d.VH && vx < d.VW) {
+                        float v = y[jj] * sc + sh;
+                        ssum += v;
+                        ssq += v * v;
+                        const size_t pix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
+                        if (res_n) v += res_n[pix * d.res_cstride + co];
+                        if (d.act == ADH_ACT_RELU) v = fmaxf(v, 0.f);
+                        out_n[pix * d.out_cstride + co] = v;
+                    }
+                }
+            }
+        }
+        if (d.stats) {
+            if (j) __builtin_amdgcn_s_barrier();
+            red[(0 * 8 + (tid >> 5)) * 32 + cl] = ssum;
+            red[(1 * 8 + (tid >> 5)) * 32 + cl] = ssq;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < 64) {
+                const int which = tid >> 5;
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v += red[(which * 8 + r) * 32 + cl];
+                d.stats[((size_t)region * 2 + which) * d.NcP + co0 + j * 32 + cl] = v;
+            }
+        }
+    }
+}
+
+// eligibility + geometry of the F(3x3,2x2) path: forward-walking 2x2 taps on the in_s-subsampled input, or the 4x4 s2
+// convolution as four input-parity classes
+static int wino32_plan(const adh_conv_desc* d, Wino32Geom* g) {
+    static const bool enabled = !(getenv("ADH_WINO32") && atoi(getenv("ADH_WINO32")) == 0);   // A/B switch
+    if (!enabled || !d) return 0;
+    if (d->Cin % W2_KC != 0 || d->in_cstride % 4 != 0 || d->NcP % 32 != 0) return 0;
+    if (d->in_sy != d->in_sx || d->dstep_y != d->dstep_x || d->out_sy != d->out_sx) return 0;
+    if ((int64_t)(d->IH + 2) * d->IW * d->in_cstride >= (1ll << 29) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 31))
+        return 0;
+    if (d->KH == 2 && d->KW == 2 && d->dstep_y == d->in_sy && (d->in_sy == 1 || d->in_sy == 2)) {
+        g->ncls = 1; g->xps = d->in_sy;
+        for (int c = 0; c < 4; ++c) { g->ymin[c] = d->dy0; g->xmin[c] = d->dx0; }
+    } else if (d->KH == 4 && d->KW == 4 && d->in_sy == 2 && d->dstep_y == 1) {
+        g->ncls = 4; g->xps = 2;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) { g->ymin[py * 2 + px] = d->dy0 + py; g->xmin[py * 2 + px] = d->dx0 + px; }
+    } else {
+        return 0;
+    }
+    g->tiles_x = adh_ceil_div(d->VW, 48);
+    g->tiles_y = adh_ceil_div(d->VH, 12);
+    g->nregions = g->tiles_x * g->tiles_y * d->N;
+    g->nchunks = d->Cin / W2_KC;
+    g->KQtot = d->Cin / 4;
+    g->wcls = 16 * g->KQtot * d->NcP * 4;
+    return 1;
+}
+
+extern "C" int adh_conv_wino32_supported(const adh_conv_desc* d) {
+    Wino32Geom g;
+    return wino32_plan(d, &g);
+}
+
+extern "C" int adh_conv_wino32_num_blocks(const adh_conv_desc* d) {
+    Wino32Geom g;
+    if (!wino32_plan(d, &g)) return ADH_E_UNSUPPORTED;
+    return g.nregions;
+}
+
+template <int NT>
+static int launch_wino32(hipStream_t s, const adh_conv_desc* d, Wino32Geom g) {
+    g.ncog = d->NcP / (32 * NT);
+    const int nblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_wino32_kernel<NT>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, *d, g);
+    return adh_check_launch();
+}
+
+extern "C" int adh_conv_wino32_forward(void* stream, const adh_conv_desc* d) {
+    Wino32Geom g;
+    if (!wino32_plan(d, &g)) return ADH_E_UNSUPPORTED;
+    if (!d->in || !d->out || !d->wp || d->NcP < d->Cout) return ADH_E_ARG;
+    if (d->out_cstride < d->Cout || (d->residual && d->res_cstride < d->Cout)) return ADH_E_ARG;
+    if ((d->VH - 1) * d->out_sy + d->out_oy >= d->OH || (d->VW - 1) * d->out_sx + d->out_ox >= d->OW || d->out_oy < 0 ||
+        d->out_ox < 0)
+        return ADH_E_ARG;
+    if (((uintptr_t)d->in & 15) || ((uintptr_t)d->wp & 15)) return ADH_E_ARG;
+    const int nt = d->NcP / 32;
+    hipStream_t s = (hipStream_t)stream;
+    if (nt % 3 == 0) return launch_wino32<3>(s, d, g);
+    if (nt % 2 == 0) return launch_wino32<2>(s, d, g);
+    return launch_wino32<1>(s, d, g);
+}
+
+// U[cls][f = a*4+b][k/4][n][4] = (A g_cls A^T)[a][b], A = [[1,0],[1,1],[1,-1],[0,-1]]; g_cls[ty][tx] is tap
+// (ty*cstep + cy, tx*cstep + cx) of the layout L: cstep = 1, one class for a 2x2 layout; cstep = 2, four classes
+// (cy, cx) for a 4x4 layout
+__global__ void pack_weights_wino32_kernel(const float* __restrict__ src, const adh_wlayout L, int KQ, int NcP, int ncls,
+                                           f32x4* __restrict__ wp) {
+    const int64_t total = (int64_t)ncls * KQ * NcP;
+    const int cstep = ncls == 4 ? 2 : 1;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % NcP);
+        int64_t r = idx / NcP;
+        const int kq = (int)(r % KQ);
+        const int cls = (int)(r / KQ);
+        const int cy = cls >> 1, cx = cls & 1;
+        f32x4 u[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) u[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n < L.Nc) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kq * 4 + j;
+                if (k >= L.K) continue;
+                float gg[2][2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        gg[a][b] = src[(int64_t)L.tap_off0 + (a * cstep + cy) * L.tap_off_sy + (b * cstep + cx) * L.tap_off_sx +
+                                       (int64_t)k * L.stride_k + (int64_t)n * L.stride_n];
+                float tt[4][2];   // A g
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    tt[0][b] = gg[0][b];
+                    tt[1][b] = gg[0][b] + gg[1][b];
+                    tt[2][b] = gg[0][b] - gg[1][b];
+                    tt[3][b] = -gg[1][b];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {   // (A g) A^T
+                    u[a * 4 + 0][j] = tt[a][0];
+                    u[a * 4 + 1][j] = tt[a][0] + tt[a][1];
+                    u[a * 4 + 2][j] = tt[a][0] - tt[a][1];
+                    u[a * 4 + 3][j] = -tt[a][1];
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) wp[(((int64_t)cls * 16 + f) * KQ + kq) * NcP + n] = u[f];
+    }
+}
+
+extern "C" int adh_pack_weights_wino32(void* stream, const float* src, const adh_wlayout* L, float* wp) {
+    if (!src || !L || !wp || L->K < 1 || L->Nc < 1) return ADH_E_ARG;
+    if (!((L->KHt == 2 && L->KWt == 2) || (L->KHt == 4 && L->KWt == 4))) return ADH_E_ARG;
+    const int ncls = L->KHt == 4 ? 4 : 1;
+    const int KQ = adh_round_up(L->K, 8) / 4;
+    const int NcP = adh_round_up(L->Nc, 32);
+    const int64_t total = (int64_t)ncls * KQ * NcP;
+    hipLaunchKernelGGL(pack_weights_wino32_kernel, dim3(adh_min_i(adh_ceil_div(total, 128), 4096)), dim3(128), 0,
+                       (hipStream_t)stream, src, *L, KQ, NcP, ncls, reinterpret_cast<f32x4*>(wp));
+    return adh_check_launch();
+}
+
 // U[f = a*4+b][k/4][n][4] = (G g G^T)[a][b] for every (k, n); g taken through the same adh_wlayout as the direct
 // pack (so the flipped / transposed dgrad filters come for free)
 __global__ void pack_weights_wino_kernel(const float* __restrict__ src, const adh_wlayout L, int KQ, int NcP,

@@ -287,6 +287,25 @@ class Engine:
                 else:
                     d.dy0 = d.dx0 = gm["dy0"]
                     d.dstep_y = d.dstep_x = gm["dstep"]
+            if not wino and USE_WINOGRAD and Kp % 16 == 0 and \
+                    ((gm["KH"] == 2 and gm["KW"] == 2 and gm["in_s"] == 1 and gm["dstep"] in (1, -1)) or
+                     (gm["KH"] == 4 and gm["KW"] == 4 and gm["in_s"] == 2 and gm["dstep"] == 1)):
+                # F(3x3,2x2): 2x2-tap forms (one parity class of a transposed conv / of a k4 s2 data gradient) and the
+                # k4 s2 forms as four input-parity classes.  Backward-walking taps = forward-walking with the filter flipped.
+                Lw = L
+                if gm["dstep"] == -1:
+                    Lw = WLayout(L.K, L.Nc, 2, 2, L.tap_off0 + L.tap_off_sy + L.tap_off_sx, -L.tap_off_sy, -L.tap_off_sx,
+                                 L.stride_k, L.stride_n)
+                    d.dy0, d.dx0 = gm["dy0"] - 1, gm["dx0"] - 1
+                    d.dstep_y = d.dstep_x = 1
+                if H.value("adh_conv_wino32_supported", C.byref(d)):
+                    wino = 32
+                    ncls = 4 if gm["KH"] == 4 else 1
+                    wp = self._f(ncls * 16 * (Kp // 4) * NcP * 4)
+                    H.call("adh_pack_weights_wino32", w.data_ptr(), C.byref(Lw), wp.data_ptr())
+                else:
+                    d.dy0 = d.dx0 = gm["dy0"]
+                    d.dstep_y = d.dstep_x = gm["dstep"]
             if not wino:
                 wp = self._pack(w, L)   # keep alive until the launch below is enqueued
             d.wp = wp.data_ptr()
@@ -296,7 +315,8 @@ class Engine:
                 d.residual = residual.data_ptr()
                 d.res_cstride = residual.stride(2)
             d.act = act
-            nb = H.value("adh_conv_wino_num_blocks" if wino else "adh_conv_num_blocks", C.byref(d))
+            nb = H.value("adh_conv_wino32_num_blocks" if wino == 32 else
+                         ("adh_conv_wino_num_blocks" if wino else "adh_conv_num_blocks"), C.byref(d))
             descs.append((d, nb, wp, wino))
             total_blocks += nb
         stats = None
@@ -311,7 +331,9 @@ class Engine:
                 d.stats = stats.data_ptr() + row * 2 * d.NcP * 4
             # algorithmic FLOPs of this launch: 2 * virtual pixels * taps * real K * real Nc (Winograd executes 4/9)
             work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
-            if wino:
+            if wino == 32:
+                H.call("adh_conv_wino32_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
+            elif wino:
                 H.call("adh_conv_wino_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
             else:
                 H.call("adh_conv_forward", C.byref(d), work=work)

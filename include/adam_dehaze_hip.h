@@ -100,6 +100,15 @@ int adh_conv_wino_forward(void* stream, const adh_conv_desc* d);
  * adh_conv_forward, whose kernels use other region shapes */
 int adh_conv_wino_num_blocks(const adh_conv_desc* d);
 int adh_pack_weights_wino(void* stream, const float* src, const adh_wlayout* L, float* wp);
+/* Winograd F(3x3,2x2) path for the 2x2-tap gather forms (KH = KW = 2, dstep == in_s: a parity class of
+ * ConvTranspose2d k4 s2 or of a k4 s2 data gradient) and for KH = KW = 4, in_s = 2, dstep = 1 (Conv2d k4 s2 / the data
+ * gradient of ConvTranspose2d k4 s2, as four input-parity classes); Cin % 16 == 0.  d->wp packed by
+ * adh_pack_weights_wino32 (L = the 2x2 layout, or the 4x4 layout for the four-class form):
+ * [classes][16][K/4][NcP][4] floats.  Same fused epilogue; statistics rows = adh_conv_wino32_num_blocks. */
+int adh_conv_wino32_supported(const adh_conv_desc* d);
+int adh_conv_wino32_num_blocks(const adh_conv_desc* d);
+int adh_conv_wino32_forward(void* stream, const adh_conv_desc* d);
+int adh_pack_weights_wino32(void* stream, const float* src, const adh_wlayout* L, float* wp);
 /* weight gradient of the gather form: slab[s][tap][KP][NcP] partial sums over `nsplit` pixel
  * ranges (KP = Cin rounded up to 32); d->out is the gradient wrt the conv output. */
 int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab, int nsplit);
