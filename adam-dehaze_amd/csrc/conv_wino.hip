@@ -744,6 +744,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     const int cl = tid & 31;
     float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
     const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
+    const bool full = vy0 + 12 <= d.VH && vx0 + 48 <= d.VW && co0 + 32 * NT <= d.Cout;
+    const int ocs = d.out_cstride * 4, rcs = d.res_cstride * 4;
+    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(out_n, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr_ =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res_n ? res_n : d.in), 0, 0x7fffffff, 0x00020000);
+    const int ovoff = 3 * (tid >> 5) * d.out_sx * ocs + cl * 4, rvoff = 3 * (tid >> 5) * d.out_sx * rcs + cl * 4;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         __builtin_amdgcn_s_barrier();   // V / raw (first tile) or the previous tile's M fully consumed
@@ -763,14 +769,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
         const float sc = (d.scale && cvalid) ? d.scale[co] : 1.f;
         const float sh = (d.shift && cvalid) ? d.shift[co] : 0.f;
         float ssum = 0.f, ssq = 0.f;
-#pragma unroll 1
-        for (int p = 0; p < 8; ++p) {
-            const int t = (tid >> 5) + 8 * p;
-            const int trow = t >> 4, tc = t & 15;
+        // y[3][3] = G^T M G of tile t for channel cl
+        auto out_tile = [&](int t, float (&y)[3][3]) {
             float m[16];
 #pragma unroll
             for (int f = 0; f < 16; ++f) m[f] = M[(f * W2_TILES + t) * 32 + cl];
-            // G^T M: rows 0..2 from frequency rows 0..3
             float u[3][4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -782,19 +785,64 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float hs = 0.5f * (u[i][1] + u[i][2]), hd = 0.5f * (u[i][1] - u[i][2]);
-                const float y[3] = {u[i][0] + hs, hd, hs + u[i][3]};
-                const int vy = vy0 + 3 * trow + i;
+                y[i][0] = u[i][0] + hs;
+                y[i][1] = hd;
+                y[i][2] = hs + u[i][3];
+            }
+        };
+        if (full) {
+            // whole region inside the virtual grid, all 32 channels real: no predicates; every global address is the
+            // per-thread constant voffset plus a scalar offset
+            const int cbytes = (co0 + j * 32) * 4;
+            auto opix = [&](int p, int i, int jj) {
+                return ((vy0 + 3 * (p >> 1) + i) * d.out_sy + d.out_oy) * d.OW + (vx0 + 24 * (p & 1) + jj) * d.out_sx + d.out_ox;
+            };
+#pragma unroll 2
+            for (int p = 0; p < 8; ++p) {
+                float y[3][3];
+                out_tile((tid >> 5) + 8 * p, y);
+                float rv[3][3];
+                if (res_n) {
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) {
-                    const int vx = vx0 + 3 * tc + jj;
-                    if (cvalid && vy < d.VH && vx < d.VW) {
-                        float v = y[jj] * sc + sh;
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 3; ++jj)
+                            rv[i][jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr_, rvoff, opix(p, i, jj) * rcs + cbytes, 0));
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) {
+                        float v = y[i][jj] * sc + sh;
                         ssum += v;
                         ssq += v * v;
-                        const size_t pix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
-                        if (res_n) v += res_n[pix * d.res_cstride + co];
+                        if (res_n) v += rv[i][jj];
                         if (d.act == ADH_ACT_RELU) v = fmaxf(v, 0.f);
-                        out_n[pix * d.out_cstride + co] = v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), or_, ovoff, opix(p, i, jj) * ocs + cbytes, 0);
+                    }
+            }
+        } else {
+#pragma unroll 1
+            for (int p = 0; p < 8; ++p) {
+                const int t = (tid >> 5) + 8 * p;
+                const int trow = t >> 4, tc = t & 15;
+                float y[3][3];
+                out_tile(t, y);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int vy = vy0 + 3 * trow + i;
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) {
+                        const int vx = vx0 + 3 * tc + jj;
+                        if (cvalid && vy < d.VH && vx < d.VW) {
+                            float v = y[i][jj] * sc + sh;
+                            ssum += v;
+                            ssq += v * v;
+                            const size_t pix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
+                            if (res_n) v += res_n[pix * d.res_cstride + co];
+                            if (d.act == ADH_ACT_RELU) v = fmaxf(v, 0.f);
+                            out_n[pix * d.out_cstride + co] = v;
+                        }
                     }
                 }
             }

@@ -261,7 +261,8 @@ def main():
     for _ in range(args.warmup):
         step()
     # timed region: exactly K steps between barrier + synchronize on both sides
-    timer = H.KernelTimer({"adh_conv_forward", "adh_conv_wino_forward", "adh_conv_wgrad", "adh_conv_wgrad_wino"})
+    timer = H.KernelTimer({"adh_conv_forward", "adh_conv_wino_forward", "adh_conv_wino32_forward", "adh_conv_wgrad",
+                           "adh_conv_wgrad_wino"})
     H.TIMER = timer
     if world > 1:
         dist.barrier()
@@ -283,8 +284,10 @@ def main():
         ks = timer.summary()
         zero = {"launches": 0, "seconds": 0.0, "work": 0.0, "work_exec": 0.0}
         names = {"adh_conv_wino_forward": "conv_wino_kernel (Winograd F(2x2,3x3) fwd + dgrad launches)",
-                 "adh_conv_forward": "conv_rows_kernel / conv_igemm_kernel (direct fwd + dgrad launches: k4 s2, "
-                                     "transposed, stems, heads)",
+                 "adh_conv_wino32_forward": "conv_wino32_kernel (Winograd F(3x3,2x2) fwd + dgrad of the k4 s2 / transposed "
+                                            "layers)",
+                 "adh_conv_forward": "conv_rows_kernel / conv_igemm_kernel (direct fwd + dgrad launches: stems, heads, "
+                                     "ragged shapes)",
                  "adh_conv_wgrad_wino": "conv_wgrad_rows_kernel<WINO> (Winograd-domain weight gradients of 3x3 s1)",
                  "adh_conv_wgrad": "conv_wgrad_rows_kernel / conv_wgrad_kernel (direct weight gradients)"}
         per = {}
