@@ -358,3 +358,40 @@ def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, monkeypatch)
     scale = float(ref.abs().max())
     assert float((got[False] - ref).abs().max()) < 2e-5 * scale
     assert float((got[True] - ref).abs().max()) < 2e-5 * scale
+
+@pytest.mark.parametrize("kind,N,Ci,Co,Hh,Ww", [("conv", 1, 32, 96, 48, 96), ("conv", 2, 16, 64, 26, 50), ("conv", 1, 96, 192, 24, 192),
+                                                ("convT", 1, 64, 96, 12, 48), ("convT", 2, 32, 32, 13, 25), ("convT", 1, 16, 192, 24, 96)])
+def test_winograd32_matches_direct_path(kind, N, Ci, Co, Hh, Ww, monkeypatch):
+    """k4 s2 convolution / transposed convolution and their data gradients through conv_wino32_kernel (F(3x3,2x2), one or
+    four input-parity classes) and through the direct kernels: outputs, BatchNorm partial statistics and the fused
+    residual + ReLU epilogue agree to fp32 rounding; full and ragged 12x48 regions."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(Ci * 13 + Hh)
+    x = torch.randn(N, Hh, Ww, Ci, generator=g).to(DEV)
+    if kind == "conv":
+        w = (torch.randn(Co, Ci, 4, 4, generator=g) / (Ci * 16) ** 0.5).to(DEV)
+        OH, OW = Hh // 2, Ww // 2
+    else:
+        w = (torch.randn(Ci, Co, 4, 4, generator=g) / (Ci * 4) ** 0.5).to(DEV)
+        OH, OW = Hh * 2, Ww * 2
+    b = torch.randn(Co, generator=g).to(DEV)
+    res = torch.randn(N, OH, OW, Co, generator=g).to(DEV)
+    gy = torch.randn(N, OH, OW, Co, generator=g).to(DEV)
+    got = {}
+    for wino in (False, True):
+        monkeypatch.setattr(E, "USE_WINOGRAD", wino)
+        eng = Engine(torch.device(DEV), record=False)
+        plans = eng._launch_plan(kind, 4, 2, 1, w, "fwd")
+        y = torch.zeros(N, OH, OW, Co, device=DEV)
+        stats, nblk = eng._run_gather(plans, Act(x), y, Co, w, shift=b, want_stats=True)
+        y2 = torch.zeros(N, OH, OW, Co, device=DEV)
+        eng._run_gather(plans, Act(x), y2, Co, w, shift=b, residual=res, act=1)
+        gx = torch.zeros(N, Hh, Ww, Ci, device=DEV)
+        eng._run_gather(eng._launch_plan(kind, 4, 2, 1, w, "dgrad"), Act(gy, Co), gx, Ci, w)
+        torch.cuda.synchronize()
+        got[wino] = (y.cpu(), stats.view(nblk, 2, -1).double().sum(0)[:, :Co].cpu(), y2.cpu(), gx.cpu())
+    for i in (0, 2, 3):
+        scale = float(got[False][i].abs().max())
+        assert max_abs(got[True][i], got[False][i]) < 6e-6 * scale, i
+    ref_s = got[False][1]
+    assert float((got[True][1] - ref_s).abs().max()) < 2e-5 * float(ref_s.abs().max())
