@@ -74,6 +74,29 @@ def cpu_baseline(h, w, threads):
             "sample": f"2 images {h}x{w}, CORUN-Complex train fwd + L1 + bwd, 1 iteration, {dt:.1f} s, torch CPU oracle"}
 
 
+_PMC_PREFIX = {"adh_conv_wino_forward": "void conv_wino_kernel<", "adh_conv_wino32_forward": "void conv_wino32_kernel<",
+               "adh_conv_wgrad_wino": "void conv_wgrad_rows_kernel<3, 3, false", "adh_conv_wgrad": "void conv_wgrad_",
+               "adh_conv_forward": "void conv_rows_kernel<"}
+
+
+def pmc_traffic(family):
+    """Average HBM bytes per launch of the kernels behind `family`, from the committed PMC passes of this command
+    (tools/pmc_bench.sh -> profiles/r01_pmc_bench.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for
+    gfx950).  None when the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench.json")
+    try:
+        with open(path) as f:
+            ks = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    pre = _PMC_PREFIX.get(family, "")
+    sel = [v for k, v in ks.items() if pre and k.startswith(pre)]
+    n = sum(v["launches"] for v in sel)
+    if not n:
+        return None, None
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n, "profiles/r01_pmc_bench.json"
+
+
 def psnr_check(model, device):
     """PSNR / max-abs of the HIP eval output against the CPU oracle on a 1x3x128x256 frame."""
     from oracle import ref_cpu as R
@@ -302,13 +325,15 @@ def main():
                         "flops_exec_per_launch_avg": k["work_exec"] / max(1, k["launches"])}
         dom = max(per, key=lambda k_: per[k_]["seconds"])   # dominant kernel = most time inside the timed region
         d0 = per[dom]
+        traffic, traffic_src = pmc_traffic(dom)
         roofline = {"bound": "mfma", "kernel": d0["kernel"], "achieved": d0["achieved"], "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": d0["achieved"] / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": d0["achieved"] / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                     "launches": d0["launches"], "avg_launch_ms": d0["avg_launch_ms"],
                     "flops_per_launch_avg": d0["flops_exec_per_launch_avg"],
                     "algorithmic_tflops": d0["algorithmic"],
-                    "note": "achieved = executed MFMA FLOPs / HIP-event time over the timed region; traffic (PMC) is in "
-                            "profiles/ (rocprofv3 cannot run inside bench.py)",
+                    "note": "achieved = executed MFMA FLOPs / HIP-event time over the timed region; traffic comes from the "
+                            "committed rocprofv3 --pmc passes over this same command (rocprofv3 cannot run inside bench.py)",
                     "other_kernels": {k_: {kk: v for kk, v in per[k_].items() if kk != "flops_exec_per_launch_avg"}
                                       for k_ in per if k_ != dom},
                     "conv_seconds_per_step": sum(v["seconds"] for v in per.values()) / max(1, args.steps)}
