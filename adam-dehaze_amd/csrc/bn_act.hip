@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < EW_UNROLL; ++u) {
             const int64_t q = p + u * pstep;
-            f32x4 w = v[u] * sc + sh;
+            f32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = fmaf(v[u][j], sc[j], sh[j]);   // (the backward mask below repeats exactly this)
             if (residual) w += r[u];
             if (act == ADH_ACT_RELU) {
 #pragma unroll
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ y, int y_cs,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* partials, int64_t P,
-                                                            int C) {
+                                                            int C, const float* __restrict__ mask_ss) {
     __shared__ f32x4 red[2][256];
     const int CQ = C / 4;
     const int R = 256 / CQ;  // pixel rows handled concurrently
@@ -179,6 +181,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (active) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        // mask_ss = {scale[C], shift[C]} of the forward pass: the ReLU mask is recomputed from y (out is not read)
+        f32x4 msc = {0.f, 0.f, 0.f, 0.f}, msh = msc;
+        if (mask_ss) {
+            msc = *reinterpret_cast<const f32x4*>(mask_ss + c);
+            msh = *reinterpret_cast<const f32x4*>(mask_ss + C + c);
+        }
         const int64_t p0 = (int64_t)blockIdx.x * BNB_PPB;
         const int64_t p1 = p0 + BNB_PPB < P ? p0 + BNB_PPB : P;
         for (int64_t p = p0 + prow; p < p1; p += 4 * R) {
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             for (int u = 0; u < 4; ++u) {
                 const int64_t q = p + u * R < p1 ? p + u * R : p;
                 g[u] = *reinterpret_cast<const f32x4*>(g_out + q * g_cs + c);
-                if (act == ADH_ACT_RELU) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
+                if (act == ADH_ACT_RELU && !mask_ss) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
                 yy[u] = *reinterpret_cast<const f32x4*>(y + q * y_cs + c);
             }
 #pragma unroll
@@ -196,7 +204,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                     f32x4 gg = g[u];
                     if (act == ADH_ACT_RELU) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) gg[j] = o[u][j] > 0.f ? gg[j] : 0.f;
+                        for (int j = 0; j < 4; ++j) {
+                            const float ov = mask_ss ? fmaf(yy[u][j], msc[j], msh[j]) : o[u][j];
+                            gg[j] = ov > 0.f ? gg[j] : 0.f;
+                        }
                     }
                     sg += gg;
                     sgx += gg * ((yy[u] - mu) * is);
@@ -220,11 +231,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 extern "C" int adh_bn_bwd_reduce(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
                                  const float* y, int y_cs, const float* mean, const float* invstd, float* partials,
-                                 int64_t P, int C) {
+                                 int64_t P, int C, const float* mask_ss) {
     if (!g_out || !y || !mean || !invstd || !partials || P < 1 || C < 4 || (C & 3) || C > 1024) return ADH_E_ARG;
-    if (act == ADH_ACT_RELU && !out) return ADH_E_ARG;
+    if (act == ADH_ACT_RELU && !out && !mask_ss) return ADH_E_ARG;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(adh_bn_bwd_num_blocks(P, C)), dim3(256), 0, (hipStream_t)stream, g_out,
-                       g_cs, out, out_cs, act, y, y_cs, mean, invstd, partials, P, C);
+                       g_cs, out, out_cs, act, y, y_cs, mean, invstd, partials, P, C, mask_ss);
     return adh_check_launch();
 }
 
@@ -274,14 +285,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, int training,
                                                            float* __restrict__ g_y, int gy_cs, float* __restrict__ g_res,
-                                                           int gres_cs, int64_t P, int C) {
+                                                           int gres_cs, int64_t P, int C, const float* __restrict__ mask_ss) {
     const int CQ = C / 4;
     const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int64_t pstep = (int64_t)gridDim.x * 256 / CQ;
     int64_t p = t / CQ;
     const int c = (int)(t - p * CQ) * 4;
     const f32x4 k0 = *reinterpret_cast<const f32x4*>(coef + c);
-    f32x4 mg = {0.f, 0.f, 0.f, 0.f}, kx = mg, mu = mg;
+    f32x4 mg = {0.f, 0.f, 0.f, 0.f}, kx = mg, mu = mg, msc = mg, msh = mg;
+    if (mask_ss) {
+        msc = *reinterpret_cast<const f32x4*>(mask_ss + c);
+        msh = *reinterpret_cast<const f32x4*>(mask_ss + C + c);
+    }
     if (training) {
         mg = *reinterpret_cast<const f32x4*>(coef + C + c);
         const f32x4 mgx = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         for (int u = 0; u < EW_UNROLL; ++u) {
             const int64_t q = p + u * pstep < P ? p + u * pstep : p;
             g[u] = *reinterpret_cast<const f32x4*>(g_out + q * g_cs + c);
-            if (act == ADH_ACT_RELU) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
+            if (act == ADH_ACT_RELU && !mask_ss) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
             if (training) yy[u] = *reinterpret_cast<const f32x4*>(y + q * y_cs + c);
         }
 #pragma unroll
@@ -304,7 +319,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 f32x4 gg = g[u];
                 if (act == ADH_ACT_RELU) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) gg[j] = o[u][j] > 0.f ? gg[j] : 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        const float ov = mask_ss ? fmaf(yy[u][j], msc[j], msh[j]) : o[u][j];
+                        gg[j] = ov > 0.f ? gg[j] : 0.f;
+                    }
                 }
                 if (g_res) *reinterpret_cast<f32x4*>(g_res + q * gres_cs + c) = gg;
                 f32x4 r;
@@ -318,11 +336,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 extern "C" int adh_bn_bwd_apply(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
                                 const float* y, int y_cs, const float* mean, const float* invstd, const float* coef,
-                                int training, float* g_y, int gy_cs, float* g_res, int gres_cs, int64_t P, int C) {
+                                int training, float* g_y, int gy_cs, float* g_res, int gres_cs, int64_t P, int C,
+                                const float* mask_ss) {
     if (!g_out || !coef || !g_y || P < 1 || C < 4 || (C & 3)) return ADH_E_ARG;
     if (training && (!y || !mean || !invstd)) return ADH_E_ARG;
-    if (act == ADH_ACT_RELU && !out) return ADH_E_ARG;
+    if (mask_ss && !(training && act == ADH_ACT_RELU)) return ADH_E_ARG;
+    if (act == ADH_ACT_RELU && !out && !mask_ss) return ADH_E_ARG;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P, C / 4)), dim3(256), 0, (hipStream_t)stream, g_out, g_cs, out, out_cs, act,
-                       y, y_cs, mean, invstd, coef, training, g_y, gy_cs, g_res, gres_cs, P, C);
+                       y, y_cs, mean, invstd, coef, training, g_y, gy_cs, g_res, gres_cs, P, C, mask_ss);
     return adh_check_launch();
 }

@@ -416,7 +416,7 @@ class Engine:
         partial = self._f(nblk, 2, C4)
         zeros = self._f(C4, zero=True)
         H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), None, 0, H.ACT_NONE, g.data_ptr(), g.stride(2),
-               zeros.data_ptr(), zeros.data_ptr(), partial.data_ptr(), P, C4)
+               zeros.data_ptr(), zeros.data_ptr(), partial.data_ptr(), P, C4, None)
         dbeta = self._f(C4)
         coef = self._f(3, C4)
         H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), None, zeros.data_ptr(), None,
@@ -451,7 +451,8 @@ class Engine:
             # raw conv output + per-block statistics, then normalise (+residual, ReLU) in one streaming pass
             y = self._f(N, OH, OW, _round_up(Cout, 4))
             stats, nblk = self._run_gather(plans, x, y, Cout, w, shift=b, want_stats=True)
-            scale, shift = self._f(Cout), self._f(Cout)
+            ss = self._f(2, _round_up(Cout, 4), zero=True)   # {scale, shift}: kept for the backward ReLU mask
+            scale, shift = ss[0], ss[1]
             mean, invstd = self._f(Cout), self._f(Cout)
             NcP = _round_up(Cout, 32)
             H.call("adh_bn_finalize", stats.data_ptr(), nblk, NcP, Cout, float(P), bn.weight.data_ptr(),
@@ -461,7 +462,7 @@ class Engine:
                 bn.num_batches_tracked += 1
             H.call("adh_bn_apply", y.data_ptr(), y.stride(2), scale.data_ptr(), shift.data_ptr(), H.ptr(res_t),
                    res_t.stride(2) if res_t is not None else 0, act_code, out.data_ptr(), out.stride(2), P, Cout)
-            saved = ("train", y, mean, invstd)
+            saved = ("train", y, mean, invstd, ss)
         elif bn is not None:
             scale, shift = self._f(Cout), self._f(Cout)
             H.call("adh_bn_fold_eval", Cout, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
@@ -494,17 +495,20 @@ class Engine:
         if residual is not None and residual.needs_grad:
             g_res = self._f(N, OH, OW, C4)
         if mode == "train":
-            _, y, mean, invstd = saved
+            _, y, mean, invstd, ss = saved
+            # without a residual the ReLU mask is recomputed from y (fma(y, scale, shift) > 0, the forward expression):
+            # the two backward passes then read two tensors each instead of three
+            mask_ss = ss.data_ptr() if (relu and residual is None) else None
             nblk = H.value("adh_bn_bwd_num_blocks", P, C4)
             partial = self._f(nblk, 2, C4)
             H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
-                   y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4)
+                   y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4, mask_ss)
             dgamma, dbeta, coef = self._f(C4), self._f(C4), self._f(3, C4)
             H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), bn.weight.data_ptr(),
                    invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
             H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
                    y.stride(2), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), 1, g_y.data_ptr(), g_y.stride(2),
-                   H.ptr(g_res), g_res.stride(2) if g_res is not None else 0, P, C4)
+                   H.ptr(g_res), g_res.stride(2) if g_res is not None else 0, P, C4, mask_ss)
             self.add_param_grad(bn.weight, dgamma[:Cout])
             self.add_param_grad(bn.bias, dbeta[:Cout])
             if b is not None:   # a bias feeding train-mode BN has an exactly zero gradient
@@ -517,7 +521,7 @@ class Engine:
                 coef[0].fill_(1.0)
             H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, None, 0, None, None,
                    coef.data_ptr(), 0, g_y.data_ptr(), g_y.stride(2), H.ptr(g_res),
-                   g_res.stride(2) if g_res is not None else 0, P, C4)
+                   g_res.stride(2) if g_res is not None else 0, P, C4, None)
             if mode == "eval":
                 # frozen-statistics BN: dgamma = sum(g*xhat), dbeta = sum(g); xhat recovered from the conv output is
                 # not kept in eval mode, so only dbeta/dbias are produced (enough for the eval-mode fixtures).

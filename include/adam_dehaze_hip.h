@@ -157,9 +157,11 @@ int adh_bn_apply(void* stream, const float* y, int y_cs, const float* scale, con
  * pass 1: per-block partial sums of g and g*xhat -> partials[nblk][2][C]
  * (nblk = adh_bn_bwd_num_blocks(P)). */
 int adh_bn_bwd_num_blocks(int64_t P, int C);
+/* mask_ss (optional, act == RELU, no residual): {scale[C], shift[C]} of the forward pass -- the ReLU mask is then
+ * recomputed as fma(y, scale, shift) > 0, exactly the forward expression, and `out` is not read (one tensor pass less). */
 int adh_bn_bwd_reduce(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
                       const float* y, int y_cs, const float* mean, const float* invstd,
-                      float* partials, int64_t P, int C);
+                      float* partials, int64_t P, int C, const float* mask_ss);
 /* finalize: dgamma = sum(g*xhat), dbeta = sum(g) (accumulated into grads when accumulate!=0) and the
  * per-channel coefficients used by pass 2. coef[3][C] = {gamma*invstd, mean_g, mean_gxhat}. */
 int adh_bn_bwd_finalize(void* stream, const float* partials, int nblk, int C, double count,
@@ -169,7 +171,8 @@ int adh_bn_bwd_finalize(void* stream, const float* partials, int nblk, int C, do
  * training==0 (eval BN): g_y = g*scale only (coef row 0). */
 int adh_bn_bwd_apply(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
                      const float* y, int y_cs, const float* mean, const float* invstd, const float* coef,
-                     int training, float* g_y, int gy_cs, float* g_res, int gres_cs, int64_t P, int C);
+                     int training, float* g_y, int gy_cs, float* g_res, int gres_cs, int64_t P, int C,
+                     const float* mask_ss);
 
 /* ---- AttentionBlock (base_model.py:43-78) ----------------------------------------------------- */
 /* pooled[n][2][C] = (mean, max) over H*W; amax_idx[n][C] = first pixel index attaining the max */
