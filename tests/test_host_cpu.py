@@ -137,3 +137,31 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+[^\n]*oracle", src, flags=re.M), fn
+
+def test_counted_wait_kernels_have_no_scratch_traffic(tmp_path):
+    """conv_wino_kernel / conv_wino32_kernel fetch their weights with inline-asm loads and hand-counted vmcnt waits
+    (csrc/conv_wino.hip, w2_load_b).  A register spill inside those kernels would add scratch loads / stores that the
+    counts do not know about (and compiler waits in the middle of the counted span), so the build must stay spill-free:
+    this compiles the file to ISA on the host and checks that no instantiation touches scratch memory."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "adam-dehaze_amd", "csrc", "conv_wino.hip")
+    out = tmp_path / "conv_wino.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-S", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, timeout=900)
+    text = out.read_text()
+    kernels = {}
+    cur = None
+    for line in text.splitlines():
+        if line.startswith("_Z") and ":" in line and ("conv_wino_kernel" in line or "conv_wino32_kernel" in line):
+            cur = line.split(":")[0]
+            kernels[cur] = 0
+        elif cur and line.strip().startswith("s_endpgm"):
+            cur = None
+        elif cur and "scratch_" in line:
+            kernels[cur] += 1
+    assert len(kernels) == 6, sorted(kernels)          # NT = 1, 2, 3 of both kernels
+    assert all(v == 0 for v in kernels.values()), kernels
