@@ -5,13 +5,21 @@
 // with d->out read as G).  This is the autograd backward ATen runs for Conv2d / ConvTranspose2d in
 // the reference's training step (/root/reference training/train_joint.py:153, train_dehazing.py:96).
 //
-// Decomposition: a workgroup (4 waves) owns one 32-wide input-channel tile x (32*TN) output channels x
-// T taps and sweeps pixel tiles (TH rows x 32 columns), keeping dW in MFMA accumulators; the T*TN
-// 32x32 output tiles are dealt to the 4 waves in compile-time contiguous shares (WgShare).  Per tile the input halo [pixels][32 ch] and the G tile [pixels][32*TN] are
-// staged once in LDS (pixel-major, so the MFMA operands -- A[i=channel][k=pixel], B[k=pixel][j=channel]
-// -- are conflict-free ds_read_b32 with consecutive lanes on consecutive channels, and every tap is an
-// address offset).  The pixel dimension is split over gridDim.x workgroups; each writes its partial to
-// slab[split] and adh_wgrad_reduce sums the splits in a fixed order (deterministic, no atomics).
+// Three kernels, chosen by adh_conv_wgrad / adh_conv_wgrad_wino:
+//   * conv_wgrad_rows_kernel<KH,KW,REV,TN>          -- "row split": 3x3 s1 and the 2x2-tap forms on 4x32-aligned grids
+//                                                      (Cin % 32 == 0): k split over 4 waves, LDS-DMA staging, pinned
+//                                                      accumulators; see the block comment above that kernel;
+//   * conv_wgrad_rows_kernel<3,3,false,TN,WINO=true> -- the same skeleton accumulating in the Winograd F(2x2,3x3) domain
+//                                                      (4/9 of the MFMA work, operands transformed in registers);
+//   * conv_wgrad_kernel<T,TN> (first in this file)   -- general fallback: any tap count / ragged grids / Cin % 32 != 0 and
+//                                                      the packed 7x7 stem.  A workgroup owns one 32-wide input-channel
+//                                                      tile x 32*TN output channels x T taps and sweeps pixel tiles (TH rows
+//                                                      x 32 columns); waves 0-3 contract from LDS while waves 4-7 stage the
+//                                                      next tile through registers.
+// In all of them the input halo [pixels][32 ch] and the G tile [pixels][32*TN] sit in LDS pixel-major, so the MFMA
+// operands -- A[i=channel][k=pixel], B[k=pixel][j=channel] -- are conflict-free ds_read_b32 with consecutive lanes on
+// consecutive channels and every tap is an address offset; the pixel dimension is split over workgroups that write
+// partial slabs, summed in a fixed order by the reduce kernels (deterministic, no atomics).
 #include "common.h"
 #include <cstdlib>
 
