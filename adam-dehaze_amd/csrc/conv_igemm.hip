@@ -5,6 +5,11 @@
 // Replaces the ATen conv2d / conv_transpose2d calls behind ConvBlock and the decoder stages
 // (/root/reference models/dehazing/base_model.py:11-13, medium_intensity.py:53,63).
 //
+// This is the general kernel: adh_conv_forward first offers the launch to conv_rows_kernel (conv_rows.hip: 2x2- and
+// 3x3-tap forms on 16x32-aligned grids), and the engine routes 3x3 s1 and k4 s2 / transposed layers with Cin % 16 == 0
+// to the Winograd kernels (conv_wino.hip); what arrives here are the stems (7x7, Cin 3), the small heads, 1x1
+// convolutions and ragged grids.
+//
 // Work decomposition (per 256-thread workgroup = 4 waves, 2 workgroups per CU):
 //   tile = 8 rows x 32 columns of virtual output pixels x (32*TN) output channels;
 //   wave w owns rows 2w,2w+1 (two 32-pixel MFMA row blocks) x TN column blocks -> 2*TN accumulators.
