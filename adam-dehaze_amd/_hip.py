@@ -62,6 +62,10 @@ _SIGNATURES = {
     "adh_conv_wino32_num_blocks": [PD],
     "adh_conv_wino32_forward": [vp, PD],
     "adh_pack_weights_wino32": [vp, vp, PL, vp],
+    "adh_conv_wino43_supported": [PD],
+    "adh_conv_wino43_num_blocks": [PD],
+    "adh_conv_wino43_forward": [vp, PD],
+    "adh_pack_weights_wino43": [vp, vp, PL, vp],
     "adh_pack_weights_wino": [vp, vp, PL, vp],
     "adh_conv_wgrad": [vp, PD, vp, i32],
     "adh_conv_wgrad_wino_groups": [PD],
@@ -131,7 +135,7 @@ _SIGNATURES = {
 }
 
 # functions that return a count / size rather than a status code
-_VALUE_FUNCS = {"adh_version", "adh_conv_wino_supported", "adh_conv_wino_num_blocks", "adh_conv_wino32_supported",
+_VALUE_FUNCS = {"adh_version", "adh_conv_wino_supported", "adh_conv_wino_num_blocks", "adh_conv_wino32_supported", "adh_conv_wino43_supported", "adh_conv_wino43_num_blocks",
                 "adh_conv_wino32_num_blocks", "adh_conv_wgrad_wino_groups", "adh_conv_wgrad_slabs", "adh_conv_wgrad_groups", "adh_conv_lds_bytes", "adh_conv_num_blocks", "adh_bn_bwd_num_blocks",
                 "adh_cbam_pool_num_blocks", "adh_cbam_bwd_b_num_blocks", "adh_head_blend_bwd_num_blocks",
                 "adh_reduce_num_blocks", "adh_lpips_layer_num_blocks"}

@@ -1,0 +1,511 @@
+// Winograd F(4x4, 3x3) convolution on fp32 MFMA, gfx950: the 3x3 stride-1 pad-1 convolutions (and their data
+// gradients) at 36/144 = 1/4 of the direct algorithm's MFMA FLOPs (F(2x2,3x3) in conv_wino.hip: 4/9).  Same
+// descriptor, same fused epilogue; replaces the same ATen conv2d calls
+// (/root/reference models/dehazing/base_model.py:11-13,26-41).
+//
+//   Y(4x4) = A^T [ (G g G^T) .* (B^T d B) ] A        d: 6x6 input patch, g: 3x3 filter   (Lavin & Gray, 2015)
+//
+// Interpolation points {0, +-3/4, +-5/4, inf} instead of the textbook {0, +-1, +-2, inf}: same operation count (the
+// +- pairs keep the even/odd split), every constant still a dyadic rational, and 3-4x less rounding error -- simulated
+// in fp32 with sequential accumulation over 96..384 channels: 1.5e-6..3.4e-6 of the output scale against 5e-6..1e-5 for
+// the textbook points and 1.0e-6..1.5e-6 for the direct algorithm (point choice after Barabasz et al., "Error analysis
+// and improving the accuracy of Winograd convolution for deep neural networks", 2018).  fp32 arithmetic throughout.
+//
+// Workgroup = 4 waves x 512 registers: output region 16 rows x 32 cols = 4 x 8 tiles of 4x4 = one 32-tile
+// MFMA row block, x 32*NT output channels; the 36 frequencies are dealt 9 per wave: 9*NT accumulator tiles, the first
+// 16 pinned to AGPRs.  Per chunk of 16 input channels:
+//   * the 18 x 34 raw halo arrives by LDS-DMA in the layout [row][column mod 4][index][16 ch] (34 pixel slots per row)
+//     so that the patch columns of adjacent tiles are adjacent in LDS; every lane's source offset comes from a 612-entry
+//     table built once per workgroup (clamped coordinates: all lanes always load, out-of-image cells are zeroed after
+//     landing); 40 pieces per chunk, 10 per wave, double buffered;
+//   * the input transform runs as two 1-D passes through LDS (column pass raw -> T, row pass T -> V in place): ~12
+//     registers live instead of the 72 a 6x6 tile would need next to 27 accumulator tiles;
+//   * contraction: per wave 18 groups (9 frequencies x two 8-channel halves) of 4*NT MFMAs; A = one ds_read_b128 of
+//     V[f][tile][quad ^ swizzle(tile)], B = NT global_load_dwordx4 of U[f][k/4][n][4] (adh_pack_weights_wino43), fetched
+//     two groups ahead with hand-counted waits (conv_wino.hip, w2_load_b: same contract).
+// V is single buffered: a chunk is transformed, then contracted (VALU and fp32 MFMA work do not overlap anyway).
+// Epilogue: accumulators -> LDS M[36][32 tiles][32 co] one channel tile at a time, A^T M A and the fused epilogue.
+#include "common.h"
+#include <cstdlib>
+
+#ifndef W4_DBG
+#define W4_DBG 0   // dev builds (-DW4_DBG=n): 1 = skip the input transform, 2 = skip the contraction, 4 = skip the epilogue
+#endif
+#define W4_KC 16
+#define W4_TILES 32
+#define W4_VF (36 * W4_TILES * W4_KC)              // floats of V (73,728 B)
+#define W4_SLOTS 612                               // pixel slots of the raw halo: 18 rows x 34 columns
+#define W4_ROWSLOTS 34
+#define W4_RAWF (40 * 256)                         // floats per raw buffer: 40 DMA pieces of 16 slots (640 >= 612 slots)
+#define W4_TAB (W4_VF + 2 * W4_RAWF)               // float offset of the slot tables
+#define W4_RED (W4_TAB + 2 * 640)                  // statistics scratch
+#define W4_LDS_BYTES ((W4_RED + 2 * 8 * 32) * 4)
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr4;
+
+struct Wino43Geom {
+    int tiles_x, tiles_y;        // 32-col x 16-row regions
+    int nregions;
+    int nchunks;
+    int KQtot;
+    int ncog;
+};
+
+template <int IDX>
+__device__ __forceinline__ void w4_mfma(f32x16& c, float a, float b) {
+    if constexpr (IDX < 16) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// one group: local frequency FI, NT output-channel tiles, 4 k-steps
+template <int NT, int FI, int KK, int J>
+__device__ __forceinline__ void w4_group(f32x16 (&acc)[9 * NT], const f32x4& a, const f32x4 (&b)[NT]) {
+    if constexpr (KK < 4) {
+        w4_mfma<FI * NT + J>(acc[FI * NT + J], a[KK], b[J][KK]);
+        if constexpr (J + 1 < NT) w4_group<NT, FI, KK, J + 1>(acc, a, b);
+        else w4_group<NT, FI, KK + 1, 0>(acc, a, b);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void w4_load_b(f32x4 (&b)[NT], unsigned voff, const float* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(voff), "s"(sbase) : "memory");
+    if constexpr (NT > 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(b[1]) : "v"(voff), "s"(sbase) : "memory");
+    if constexpr (NT > 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[2]) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N, int NT>
+__device__ __forceinline__ void w4_wait_b(f32x4 (&b)[NT]) {
+    if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b[0]) : "n"(N) : "memory");
+    if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+    if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N) : "memory");
+}
+
+// Points +-a, +-b:  a = 3/4, b = 5/4
+#define W4_A 0.75f
+#define W4_B 1.25f
+#define W4_A2 0.5625f        // a^2
+#define W4_B2 1.5625f        // b^2
+#define W4_A3 0.421875f      // a^3
+#define W4_B3 1.953125f      // b^3
+#define W4_A2B2 0.87890625f  // a^2 b^2
+#define W4_S2 2.125f         // a^2 + b^2
+
+// 1-D input transform B^T (6 points), written so that at most eight float4 values are live: the results go to
+// LDS (dst + a * stride floats) as soon as they exist.  Rows of B^T = coefficients of prod_{q != p} (x - q):
+//   p = 0:    a^2 b^2 d0 - (a^2 + b^2) d2 + d4          p = +-a:  (d4 - b^2 d2) +- a (d3 - b^2 d1)
+//   p = inf:  a^2 b^2 d1 - (a^2 + b^2) d3 + d5          p = +-b:  (d4 - a^2 d2) +- b (d3 - a^2 d1)
+__device__ __forceinline__ void w4_bt_store(f32x4 (&d)[6], float* dst, int stride) {
+    d[0] = W4_A2B2 * d[0] + (d[4] - W4_S2 * d[2]);
+    *reinterpret_cast<f32x4*>(dst) = d[0];
+    d[5] = W4_A2B2 * d[1] + (d[5] - W4_S2 * d[3]);
+    *reinterpret_cast<f32x4*>(dst + 5 * stride) = d[5];
+    const f32x4 p = d[4] - W4_B2 * d[2], r = d[4] - W4_A2 * d[2];
+    const f32x4 q = d[3] - W4_B2 * d[1], s = d[3] - W4_A2 * d[1];
+    *reinterpret_cast<f32x4*>(dst + 1 * stride) = p + W4_A * q;
+    *reinterpret_cast<f32x4*>(dst + 2 * stride) = p - W4_A * q;
+    *reinterpret_cast<f32x4*>(dst + 3 * stride) = r + W4_B * s;
+    *reinterpret_cast<f32x4*>(dst + 4 * stride) = r - W4_B * s;
+}
+
+// runs the 18 groups of one chunk; GI = group index (frequency GI % 9, channel half GI / 9)
+template <int NT, int GI>
+__device__ __forceinline__ void w4_chunk(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], f32x4 (&bv)[3][NT], const float* vlane,
+                                         const float* vlane1, unsigned b_voff, const float* b_chunk, const float* b_next, int64_t b_fstride,
+                                         int b_kq2) {
+    if constexpr (GI < 18) {
+        // operands two groups ahead (weights) / one group ahead (V)
+        constexpr int G2 = GI + 2;
+        if constexpr (G2 < 18) w4_load_b<NT>(bv[G2 % 3], b_voff, b_chunk + (G2 % 9) * b_fstride + (G2 / 9) * b_kq2);
+        else w4_load_b<NT>(bv[G2 % 3], b_voff, b_next + (G2 - 18) * b_fstride);
+        if constexpr (GI + 1 < 18) {
+            constexpr int G1 = GI + 1;
+            av[G1 & 1] = *reinterpret_cast<const f32x4*>((G1 / 9 ? vlane1 : vlane) + (G1 % 9) * (W4_TILES * W4_KC));
+        }
+        w4_wait_b<2 * NT, NT>(bv[GI % 3]);
+        w4_group<NT, GI % 9, 0, 0>(acc, av[GI & 1], bv[GI % 3]);
+        w4_chunk<NT, GI + 1>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, b_kq2);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc d, const Wino43Geom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // V | raw[2] | slot tables | red ; M aliases V + raw
+    float* const rawbase = lds + W4_VF;
+    int* const tab_off = reinterpret_cast<int*>(lds + W4_TAB);          // [640] source byte offset of slot s (clamped)
+    int* const tab_ok = tab_off + 640;                                   // [640] 1 if slot s lies inside the image
+    float* const red = lds + W4_RED;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int q = bid >> 3;
+    const int cg = q % g.ncog;
+    const int region = (q / g.ncog) * 8 + (bid & 7);
+    if (region >= g.nregions) return;
+    int rr = region;
+    const int tx = rr % g.tiles_x;
+    rr /= g.tiles_x;
+    const int ty = rr % g.tiles_y;
+    const int n = rr / g.tiles_y;
+    const int oy0 = ty * 16, ox0 = tx * 32;
+    const int co0 = cg * 32 * NT;
+
+    // ------------------------------------------------------------------ slot tables: slot s = row*34 + {9,9,8,8 per plane}
+    const int xcs = d.in_cstride * 4;
+    const bool interior = oy0 >= 1 && oy0 + 17 <= d.IH && ox0 >= 1 && ox0 + 33 <= d.IW;
+    for (int s = tid; s < 640; s += 256) {
+        const int sc = s < W4_SLOTS ? s : W4_SLOTS - 1;
+        const int row = sc / W4_ROWSLOTS, rem = sc - row * W4_ROWSLOTS;
+        const int plane = rem < 9 ? 0 : (rem < 18 ? 1 : (rem < 26 ? 2 : 3));
+        const int idx = rem - (plane == 0 ? 0 : (plane == 1 ? 9 : (plane == 2 ? 18 : 26)));
+        const int iy = oy0 - 1 + row, ix = ox0 - 1 + 4 * idx + plane;
+        const int iyc = adh_min_i(adh_max_i(iy, 0), d.IH - 1), ixc = adh_min_i(adh_max_i(ix, 0), d.IW - 1);
+        tab_off[s] = (iyc * d.IW + ixc) * xcs;
+        tab_ok[s] = (s < W4_SLOTS && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) ? 1 : 0;
+    }
+    const float* in_n = d.in + (int64_t)n * d.IH * d.IW * d.in_cstride;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, 0x7fffffff, 0x00020000);
+    const int cq_l = lane & 3, px_l = lane >> 2;
+    // 40 pieces per chunk, 10 per wave: piece k = 4u + wave covers slots 16k..16k+15 (slots >= 612 repeat slot 611)
+    const int* const tab_lane = tab_off + 16 * wave + px_l;
+    auto stage_raw = [&](int c, int buf) {
+        const int cb = c * (W4_KC * 4);
+        const int lo = __builtin_amdgcn_readfirstlane((W4_VF + buf * W4_RAWF + wave * 256) * 4);
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int vo = tab_lane[64 * u] + cq_l * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + lo + u * 4096), 16, vo,
+                                                     cb, 0, 0);
+        }
+    };
+    auto fix_raw = [&](int buf) {
+        if (interior) return;
+        float* raw = rawbase + buf * W4_RAWF + wave * 256 + lane * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 10; ++u)
+            if (!tab_lane[640 + 64 * u]) *reinterpret_cast<f32x4*>(raw + u * 1024) = z;
+    };
+
+    // ------------------------------------------------------------------ input transform (two 1-D passes through LDS)
+    // thread = (tile, channel quad); pass 1 item k: patch column c = 2k + (tid >> 7); pass 2 item k: frequency row a = ...
+    const int tile_t = (tid >> 2) & 31, trow = tile_t >> 3, tcol = tile_t & 7;
+    const int csel = wave >> 1;                                                 // 0 / 1 (wave-uniform)
+    const int vslot_t = tile_t * 16 + ((cq_l ^ ((tile_t >> 1) & 3)) * 4);      // swizzled quad slot inside V[f][tile]
+    // patch pixel (row i, column c) of this thread's tile sits in raw row 4*trow + i, plane c & 3, index tcol + (c >> 2);
+    // slot offset of column c = 2k + csel inside a row: {0, 18, 1} (csel 0: planes 0, 2, 0) / {9, 26, 10} (csel 1)
+    const int rbase_t = ((4 * trow) * W4_ROWSLOTS + tcol) * 16 + cq_l * 4;
+    auto raw_off = [&](int i, int k) {
+        const int cs = k == 0 ? (csel ? 9 : 0) : (k == 1 ? (csel ? 26 : 18) : (csel ? 10 : 1));
+        return rbase_t + (i * W4_ROWSLOTS + cs) * 16;
+    };
+    auto transform = [&](int buf) {
+        const float* raw = rawbase + buf * W4_RAWF;
+        // pass 1: T[a][c] = sum_i B^T[a][i] d[i][c] for this thread's three columns c = csel, 2 + csel, 4 + csel
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int c = 2 * k + csel;
+            f32x4 dd[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dd[i] = *reinterpret_cast<const f32x4*>(raw + raw_off(i, k));
+            w4_bt_store(dd, lds + c * (W4_TILES * W4_KC) + vslot_t, 6 * W4_TILES * W4_KC);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // pass 2 (in place): V[a][b] = sum_c T[a][c] B[c][b] for this thread's three rows a = csel, 2 + csel, 4 + csel
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int a = 2 * k + csel;
+            f32x4 tt[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) tt[c] = *reinterpret_cast<const f32x4*>(lds + (a * 6 + c) * (W4_TILES * W4_KC) + vslot_t);
+            w4_bt_store(tt, lds + (a * 6) * (W4_TILES * W4_KC) + vslot_t, W4_TILES * W4_KC);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ------------------------------------------------------------------ contraction operands
+    // A: V[f = 9*wave + fi][tile = l31][slot(2g + h)], slot(q) = q ^ ((tile >> 1) & 3); g flips slot bit 1 (byte 32)
+    const int sw = (l31 >> 1) & 3;
+    const float* const vlane = lds + (wave * 9) * (W4_TILES * W4_KC) + l31 * 16 + ((h ^ sw) * 4);          // g = 0
+    const float* const vlane1 = lds + (wave * 9) * (W4_TILES * W4_KC) + l31 * 16 + (((2 + h) ^ sw) * 4);   // g = 1
+    // B: U[f][kq = 4c + 2g + h][n = co0 + 32 j + l31] (float4)
+    const unsigned b_voff = (unsigned)((h * d.NcP + l31) * 16);
+    const float* const b_wave = d.wp + ((int64_t)(wave * 9) * g.KQtot * d.NcP + co0) * 4;
+    const int64_t b_fstride = (int64_t)g.KQtot * d.NcP * 4;   // floats per frequency
+    const int b_kq = d.NcP * 4;                                // floats per channel quad
+
+    f32x16 acc[9 * NT];
+    f32x4 av[2], bv[3][NT];
+
+    // ------------------------------------------------------------------ prologue
+    __syncthreads();   // slot tables
+    w4_load_b<NT>(bv[0], b_voff, b_wave);
+    w4_load_b<NT>(bv[1], b_voff, b_wave + b_fstride);
+    stage_raw(0, 0);
+#pragma unroll
+    for (int t = 0; t < 9 * NT; ++t)   // (zeroing 9*NT*16 registers hides under the first DMA round trip)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fix_raw(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll 1
+    for (int c = 0; c < g.nchunks; ++c) {
+        const bool more = c + 1 < g.nchunks;
+        const int cn = more ? c + 1 : c;   // the last chunk re-stages itself (uniform counts)
+        // ---- transform raw(c) -> V (every wave is past the previous chunk's contraction: barrier at the loop end)
+        // the next chunk's raw tile goes into the other buffer (its last reader was the transform of chunk c - 1)
+        stage_raw(cn, (c + 1) & 1);
+        if (!(W4_DBG & 1)) transform(c & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- contraction.  In flight: the weights of groups 0 and 1 (older than the 10 DMA pieces)
+        if (!(W4_DBG & 2)) {
+            // groups 0 and 1 see the 10 DMA pieces and two later weight sets as newer operations
+            const float* b_chunk = b_wave + (int64_t)(c * 4) * b_kq;
+            const float* b_next = b_wave + (int64_t)(cn * 4) * b_kq;
+            av[0] = *reinterpret_cast<const f32x4*>(vlane);
+            // group 0
+            w4_load_b<NT>(bv[2], b_voff, b_chunk + 2 * b_fstride);
+            av[1] = *reinterpret_cast<const f32x4*>(vlane + 1 * (W4_TILES * W4_KC));
+            w4_wait_b<2 * NT + 10, NT>(bv[0]);
+            w4_group<NT, 0, 0, 0>(acc, av[0], bv[0]);
+            // group 1
+            w4_load_b<NT>(bv[0], b_voff, b_chunk + 3 * b_fstride);
+            av[0] = *reinterpret_cast<const f32x4*>(vlane + 2 * (W4_TILES * W4_KC));
+            w4_wait_b<2 * NT + 10, NT>(bv[1]);
+            w4_group<NT, 1, 0, 0>(acc, av[1], bv[1]);
+            // groups 2..17 (their waits retire the DMA pieces first: in-order return)
+            w4_chunk<NT, 2>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, 2 * b_kq);
+        }
+        fix_raw((c + 1) & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    w4_wait_b<0, NT>(bv[0]);
+    w4_wait_b<0, NT>(bv[1]);
+
+    // ---------------------------------------------------------------------- output transform A^T M A + fused epilogue
+    // One output-channel tile (32 co) at a time: accumulators -> M[36][32 tile rows][32 co] in LDS (tile t sits in row
+    // t' = t with its low three bits rotated so that the two lane halves, tiles t and t + 4, hit different banks), then
+    // thread = (tile, channel quad): float4 reads of its 6x6 frequency patch, A^T m A in two halves (output rows 0-1,
+    // 2-3: 12 + 6 float4 live next to the accumulators still waiting), 16 B stores.
+    if (W4_DBG & 4) return;
+    float* M = lds;   // spans V and the raw buffers
+    const int et = tid >> 3, eq = tid & 7;
+    const int etp = (et & ~7) | ((et & 3) << 1) | ((et >> 2) & 1);
+    const int ey0 = oy0 + 4 * (et >> 3), ex0 = ox0 + 4 * (et & 7);
+    float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
+    const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
+    const bool vec_ok = (d.out_cstride & 3) == 0 && ((uintptr_t)d.out & 15) == 0 &&
+                        (!d.residual || ((d.res_cstride & 3) == 0 && ((uintptr_t)d.residual & 15) == 0));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        __builtin_amdgcn_s_barrier();   // V / raw (first tile) or the previous tile's M fully consumed
+#pragma unroll
+        for (int fi = 0; fi < 9; ++fi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tp = 8 * (r >> 2) + ((r & 3) << 1) + h;   // row of tile (r & 3) + 8 * (r >> 2) + 4 * h
+                M[((wave * 9 + fi) * W4_TILES + tp) * 32 + l31] = acc[fi * NT + j][r];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int cq0 = co0 + j * 32 + eq * 4;
+        f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (d.scale && cq0 + e < d.Cout) sc4[e] = d.scale[cq0 + e];
+            if (d.shift && cq0 + e < d.Cout) sh4[e] = d.shift[cq0 + e];
+        }
+        const bool vec = vec_ok && cq0 + 3 < d.Cout;
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+        const float* mp = M + etp * 32 + eq * 4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 u[2][6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                f32x4 m[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(mp + (a * 6 + b) * (W4_TILES * 32));
+                const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                if (half == 0) {   // rows of A^T: [1 1 1 1 1 0], [0 a -a b -b 0], [0 a^2 a^2 b^2 b^2 0], [0 a^3 -a^3 b^3 -b^3 1]
+                    u[0][b] = m[0] + s12 + s34;
+                    u[1][b] = W4_A * d12 + W4_B * d34;
+                } else {
+                    u[0][b] = W4_A2 * s12 + W4_B2 * s34;
+                    u[1][b] = W4_A3 * d12 + W4_B3 * d34 + m[5];
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const f32x4 s12 = u[ii][1] + u[ii][2], d12 = u[ii][1] - u[ii][2], s34 = u[ii][3] + u[ii][4],
+                            d34 = u[ii][3] - u[ii][4];
+                const f32x4 y[4] = {u[ii][0] + s12 + s34, W4_A * d12 + W4_B * d34, W4_A2 * s12 + W4_B2 * s34,
+                                    W4_A3 * d12 + W4_B3 * d34 + u[ii][5]};
+                const int oy = ey0 + 2 * half + ii;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int ox = ex0 + jj;
+                    if (oy < d.OH && ox < d.OW) {
+                        f32x4 v = y[jj] * sc4 + sh4;
+                        ssum += v;
+                        ssq += v * v;
+                        const size_t pix = (size_t)oy * d.OW + ox;
+                        if (vec) {
+                            if (res_n) v += *reinterpret_cast<const f32x4*>(res_n + pix * d.res_cstride + cq0);
+                            if (d.act == ADH_ACT_RELU)
+                                v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                            *reinterpret_cast<f32x4*>(out_n + pix * d.out_cstride + cq0) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (cq0 + e < d.Cout) {
+                                    float ve = v[e];
+                                    if (res_n) ve += res_n[pix * d.res_cstride + cq0 + e];
+                                    if (d.act == ADH_ACT_RELU) ve = fmaxf(ve, 0.f);
+                                    out_n[pix * d.out_cstride + cq0 + e] = ve;
+                                }
+                        }
+                    }
+                }
+            }
+        }
+        if (d.stats) {
+            // sum over the 8 tiles of this wave (lane bits 3..5), then over the 4 waves through LDS
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    ssum[e] += __shfl_xor(ssum[e], o, 64);
+                    ssq[e] += __shfl_xor(ssq[e], o, 64);
+                }
+            }
+            if (j) __builtin_amdgcn_s_barrier();
+            if (lane < 8) {
+                *reinterpret_cast<f32x4*>(red + (0 * 4 + wave) * 32 + eq * 4) = ssum;
+                *reinterpret_cast<f32x4*>(red + (1 * 4 + wave) * 32 + eq * 4) = ssq;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < 64) {
+                const int which = tid >> 5, cl = tid & 31;
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v += red[(which * 4 + r) * 32 + cl];
+                d.stats[((size_t)region * 2 + which) * d.NcP + co0 + j * 32 + cl] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int wino43_plan(const adh_conv_desc* d, Wino43Geom* g) {
+    static const bool enabled = !(getenv("ADH_WINO43") && getenv("ADH_WINO43")[0] == '0');   // A/B switch
+    if (!enabled || !d) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1) return 0;
+    if (d->out_oy != 0 || d->out_ox != 0 || d->dy0 != -1 || d->dx0 != -1 || d->dstep_y != 1 || d->dstep_x != 1) return 0;
+    if (d->Cin % W4_KC != 0 || d->in_cstride % 4 != 0 || d->NcP % 32 != 0) return 0;
+    if (d->VH != d->OH || d->VW != d->OW || d->IH != d->OH || d->IW != d->OW) return 0;
+    if ((int64_t)(d->IH + 2) * d->IW * d->in_cstride >= (1ll << 29) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 31)) return 0;
+    g->tiles_x = adh_ceil_div(d->OW, 32);
+    g->tiles_y = adh_ceil_div(d->OH, 16);
+    g->nregions = g->tiles_x * g->tiles_y * d->N;
+    g->nchunks = d->Cin / W4_KC;
+    g->KQtot = d->Cin / 4;
+    return 1;
+}
+
+extern "C" int adh_conv_wino43_supported(const adh_conv_desc* d) {
+    Wino43Geom g;
+    return wino43_plan(d, &g);
+}
+
+extern "C" int adh_conv_wino43_num_blocks(const adh_conv_desc* d) {
+    Wino43Geom g;
+    if (!wino43_plan(d, &g)) return ADH_E_UNSUPPORTED;
+    return g.nregions;
+}
+
+template <int NT>
+static int launch_wino43(hipStream_t s, const adh_conv_desc* d, Wino43Geom g) {
+    g.ncog = d->NcP / (32 * NT);
+    const int nblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_wino43_kernel<NT>), dim3(nblocks), dim3(256), W4_LDS_BYTES, s, *d, g);
+    return adh_check_launch();
+}
+
+extern "C" int adh_conv_wino43_forward(void* stream, const adh_conv_desc* d) {
+    Wino43Geom g;
+    if (!wino43_plan(d, &g)) return ADH_E_UNSUPPORTED;
+    if (!d->in || !d->out || !d->wp || d->NcP < d->Cout) return ADH_E_ARG;
+    if (d->out_cstride < d->Cout || (d->residual && d->res_cstride < d->Cout)) return ADH_E_ARG;
+    if (((uintptr_t)d->in & 15) || ((uintptr_t)d->wp & 15)) return ADH_E_ARG;
+    const int nt = d->NcP / 32;
+    hipStream_t s = (hipStream_t)stream;
+    if (nt % 3 == 0) return launch_wino43<3>(s, d, g);
+    if (nt % 2 == 0) return launch_wino43<2>(s, d, g);
+    return launch_wino43<1>(s, d, g);
+}
+
+// U[f = a*6+b][k/4][n][4] = (G g G^T)[a][b];  row of G for point p: [1, p, p^2] / prod_{q != p} (p - q), for inf: [0, 0, 1]
+// (computed in double: the entries of G are not dyadic)
+__global__ void pack_weights_wino43_kernel(const float* __restrict__ src, const adh_wlayout L, int KQ, int NcP,
+                                           f32x4* __restrict__ wp) {
+    const int64_t total = (int64_t)KQ * NcP;
+    const double a = W4_A, b = W4_B;
+    const double n0 = a * a * b * b, na = 2.0 * a * a * (a * a - b * b), nb = 2.0 * b * b * (b * b - a * a);
+    const double G[6][3] = {{1.0 / n0, 0.0, 0.0},      {1.0 / na, a / na, a * a / na}, {1.0 / na, -a / na, a * a / na},
+                            {1.0 / nb, b / nb, b * b / nb}, {1.0 / nb, -b / nb, b * b / nb}, {0.0, 0.0, 1.0}};
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % NcP);
+        const int kq = (int)(idx / NcP);
+        double g[4][3][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kq * 4 + j;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q2 = 0; q2 < 3; ++q2)
+                    g[j][p][q2] = (n < L.Nc && k < L.K)
+                                      ? (double)src[(int64_t)L.tap_off0 + p * L.tap_off_sy + q2 * L.tap_off_sx +
+                                                    (int64_t)k * L.stride_k + (int64_t)n * L.stride_n]
+                                      : 0.0;
+        }
+        for (int f = 0; f < 36; ++f) {
+            const int fa = f / 6, fb = f - fa * 6;
+            f32x4 u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int q2 = 0; q2 < 3; ++q2) acc += G[fa][p] * G[fb][q2] * g[j][p][q2];
+                u[j] = (float)acc;
+            }
+            wp[((int64_t)f * KQ + kq) * NcP + n] = u;
+        }
+    }
+}
+
+extern "C" int adh_pack_weights_wino43(void* stream, const float* src, const adh_wlayout* L, float* wp) {
+    if (!src || !L || !wp || L->K < 1 || L->Nc < 1 || L->KHt != 3 || L->KWt != 3) return ADH_E_ARG;
+    const int KQ = adh_round_up(L->K, 8) / 4;
+    const int NcP = adh_round_up(L->Nc, 32);
+    const int64_t total = (int64_t)KQ * NcP;
+    hipLaunchKernelGGL(pack_weights_wino43_kernel, dim3(adh_min_i(adh_ceil_div(total, 128), 4096)), dim3(128), 0,
+                       (hipStream_t)stream, src, *L, KQ, NcP, reinterpret_cast<f32x4*>(wp));
+    return adh_check_launch();
+}

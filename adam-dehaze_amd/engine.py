@@ -22,6 +22,8 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 # Winograd F(2x2,3x3) for eligible 3x3 stride-1 convolutions and their data gradients (ADH_WINOGRAD=0 disables)
 USE_WINOGRAD = os.environ.get("ADH_WINOGRAD", "1") != "0"
+# F(4x4,3x3) where it applies, else F(2x2,3x3): True / False, or "fwd" / "dgrad" to restrict it to one direction
+USE_WINO43 = {"0": False, "1": True}.get(os.environ.get("ADH_WINO43", "1"), os.environ.get("ADH_WINO43", "1"))
 _WINO_ONLY = os.environ.get("ADH_WINOGRAD_ONLY", "")   # dev: "fwd" or "dgrad" restricts the Winograd path to one direction
 
 
@@ -102,6 +104,9 @@ class Engine:
         self.params: Dict[int, torch.Tensor] = {}
         self.alias: Dict[int, int] = {}                  # id(reshaped view of a param) -> id(param)
         self.upstream: Dict[str, torch.Tensor] = {}      # 'g': device scalar cotangent of a scalar loss
+        # None: follow USE_WINO43.  The loss networks set "dgrad": they difference the features of two nearly equal
+        # images behind max-pools, so their forward pass keeps F(2x2,3x3) (whose rounding is below the direct kernel's)
+        self.wino43: Optional[str] = None
 
     # ------------------------------------------------------------------ helpers
     def _f(self, *shape, zero=False):
@@ -279,8 +284,17 @@ class Engine:
                                  -L.tap_off_sx, L.stride_k, L.stride_n)
                     d.dy0 = d.dx0 = -1
                     d.dstep_y = d.dstep_x = 1
-                wino = bool(H.value("adh_conv_wino_supported", C.byref(d)))
-                if wino:
+                w43 = USE_WINO43 if (self.wino43 is None or USE_WINO43 is not True) else self.wino43
+                if (w43 is True or w43 == ("dgrad" if gm["dstep"] == -1 else "fwd")) and \
+                        H.value("adh_conv_wino43_supported", C.byref(d)):
+                    wino = 43
+                    wp = self._f(36 * (Kp // 4) * NcP * 4)
+                    H.call("adh_pack_weights_wino43", w.data_ptr(), C.byref(Lw), wp.data_ptr())
+                else:
+                    wino = bool(H.value("adh_conv_wino_supported", C.byref(d)))
+                if wino == 43:
+                    pass
+                elif wino:
                     KQ = Kp // 4
                     wp = self._f(16 * KQ * NcP * 4)
                     H.call("adh_pack_weights_wino", w.data_ptr(), C.byref(Lw), wp.data_ptr())
@@ -315,8 +329,8 @@ class Engine:
                 d.residual = residual.data_ptr()
                 d.res_cstride = residual.stride(2)
             d.act = act
-            nb = H.value("adh_conv_wino32_num_blocks" if wino == 32 else
-                         ("adh_conv_wino_num_blocks" if wino else "adh_conv_num_blocks"), C.byref(d))
+            nb = H.value({32: "adh_conv_wino32_num_blocks", 43: "adh_conv_wino43_num_blocks", True: "adh_conv_wino_num_blocks",
+                          False: "adh_conv_num_blocks"}[wino], C.byref(d))
             descs.append((d, nb, wp, wino))
             total_blocks += nb
         stats = None
@@ -331,7 +345,9 @@ class Engine:
                 d.stats = stats.data_ptr() + row * 2 * d.NcP * 4
             # algorithmic FLOPs of this launch: 2 * virtual pixels * taps * real K * real Nc (Winograd executes 4/9)
             work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
-            if wino == 32:
+            if wino == 43:
+                H.call("adh_conv_wino43_forward", C.byref(d), work=work, work_exec=work * 0.25)
+            elif wino == 32:
                 H.call("adh_conv_wino32_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
             elif wino:
                 H.call("adh_conv_wino_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)

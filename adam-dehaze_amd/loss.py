@@ -126,8 +126,10 @@ class _ContentFn(torch.autograd.Function):
         scale = 1.0 / len(taps)
         # target features: no gradient
         eng_t = Engine(pred.device, False)
+        eng_t.wino43 = "dgrad"
         feats_t = module._features(eng_t, target.contiguous(), taps, {})
         eng = Engine(pred.device, rec)
+        eng.wino43 = "dgrad"
         holder = {}
         feats_p = module._features(eng, pred.contiguous(), taps, holder)
         vals = []
@@ -276,8 +278,10 @@ class _LPIPSFn(torch.autograd.Function):
     def forward(ctx, module, record, pred, target):
         from .engine import Engine
         eng_t = Engine(pred.device, False)
+        eng_t.wino43 = "dgrad"
         feats_t = module._features(eng_t, target.contiguous(), {})
         eng = Engine(pred.device, record)
+        eng.wino43 = "dgrad"
         holder = {}
         feats_p = module._features(eng, pred.contiguous(), holder)
         N = pred.shape[0]

@@ -109,6 +109,16 @@ int adh_conv_wino32_supported(const adh_conv_desc* d);
 int adh_conv_wino32_num_blocks(const adh_conv_desc* d);
 int adh_conv_wino32_forward(void* stream, const adh_conv_desc* d);
 int adh_pack_weights_wino32(void* stream, const float* src, const adh_wlayout* L, float* wp);
+
+/* Winograd F(4x4,3x3) on fp32 MFMA (conv_wino43.hip): the same 3x3 stride-1 pad-1 forms as adh_conv_wino_forward at
+ * 1/4 of the direct algorithm's MFMA work (F(2x2,3x3): 4/9); needs Cin % 16 == 0.  Replaces the same ATen conv2d calls
+ * (/root/reference models/dehazing/base_model.py:11-13,26-41).  Weights: adh_pack_weights_wino43 ->
+ * [36][K/4][NcP][4] floats (U = G g G^T).  fp32 throughout; transform constants up to 8 make its rounding error
+ * ~10x the direct kernel's (still ~1e-6 relative).  Statistics rows = adh_conv_wino43_num_blocks. */
+int adh_conv_wino43_supported(const adh_conv_desc* d);
+int adh_conv_wino43_num_blocks(const adh_conv_desc* d);
+int adh_conv_wino43_forward(void* stream, const adh_conv_desc* d);
+int adh_pack_weights_wino43(void* stream, const float* src, const adh_wlayout* L, float* wp);
 /* weight gradient of the gather form: slab[s][tap][KP][NcP] partial sums over `nsplit` pixel
  * ranges (KP = Cin rounded up to 32); d->out is the gradient wrt the conv output. */
 int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab, int nsplit);

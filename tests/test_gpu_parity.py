@@ -115,7 +115,7 @@ BRANCHES = [
 ]
 
 
-@pytest.mark.parametrize("wino", [False, True], ids=["direct", "winograd"])
+@pytest.mark.parametrize("wino", [False, True, 23], ids=["direct", "winograd", "winograd-f23"])
 @pytest.mark.parametrize("name,ctor", BRANCHES)
 def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
     """Whole branches against the fixtures generated from the reference (tools/gen_golden.py).
@@ -128,7 +128,8 @@ def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
     deliberately tiny fixtures (a 7x11 bottleneck) one flipped element moves a weight gradient by a few per cent
     (measured: tools/wino_debug3.py), so that path is gated on the relative L2 error plus a looser element bound."""
     import adam_dehaze_amd.engine as E
-    monkeypatch.setattr(E, "USE_WINOGRAD", wino)
+    monkeypatch.setattr(E, "USE_WINOGRAD", bool(wino))
+    monkeypatch.setattr(E, "USE_WINO43", wino != 23)
     rec = load_golden(name)
     m = _load_into(ctor(), rec)
     x = t(rec["x"]).to(DEV)
@@ -157,8 +158,11 @@ def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
             print(f"{name:16s} {pname:44s} max-abs/scale {err / scale:.2e}  rel-L2 {rel2:.2e}  scale {scale:.2e}")
         if not wino or scale < 1e-6:   # (a bias feeding train-mode BatchNorm has a zero true gradient)
             ok = err < 5e-3 * scale + 2e-7
-        else:
+        elif wino == 23:
             ok = rel2 < 3e-2 and err < 8e-2 * scale + 2e-7
+        else:   # F(4x4,3x3) rounds ~8x coarser than F(2x2,3x3): more kink flips in these tiny fixtures; its gradients
+            # are judged against the fp64 oracle at full width in test_complex_fullwidth_vs_oracle_seeded
+            ok = rel2 < 8e-2 and err < 2e-1 * scale + 2e-7
         if not ok:
             bad.append((pname, err, scale, rel2))
     assert not bad, bad[:8]
@@ -249,13 +253,18 @@ def test_conv_transpose_vs_oracle(N, Cin, Cout, Hh, Ww):
     assert rel_err(eng.param_grads[id(bd)], br.grad) < 1e-4
 
 
-def test_complex_fullwidth_vs_oracle_seeded():
-    """Full-width CORUN-Complex (base 96) on a 2x3x64x96 synthetic foggy batch vs the CPU oracle:
+@pytest.mark.parametrize("algo", ["direct", "f23", "f43", "f43-fwd", "f43-dgrad"])
+def test_complex_fullwidth_vs_oracle_seeded(algo, monkeypatch):
+    """Full-width CORUN-Complex (base 96) on a 2x3x64x96 synthetic foggy batch vs the CPU oracle, through the direct
+    kernels, the F(2x2,3x3) and the F(4x4,3x3) Winograd kernels (the default):
     eval output, train output and L1 loss within 1e-3; parameter gradients of the smooth objective
     sum(out*g) judged against the oracle run in fp64: this 50-layer random-init train-mode network
     amplifies fp32 rounding so much that the CPU fp32 oracle itself is several % off the fp64 gradients
     for some tensors, so the HIP path must be as close to fp64 as the fp32 CPU path is (3x + 2e-3)."""
+    import adam_dehaze_amd.engine as E
     from adam_dehaze_amd.loss import l1_loss
+    monkeypatch.setattr(E, "USE_WINOGRAD", algo != "direct")
+    monkeypatch.setattr(E, "USE_WINO43", {"f43": True, "f43-fwd": "fwd", "f43-dgrad": "dgrad"}.get(algo, False))
     torch.manual_seed(42)
     m = A.HighIntensityDehazeModel()
     sd_cpu = {k: v.clone() for k, v in m.state_dict().items()}
@@ -299,7 +308,15 @@ def test_complex_fullwidth_vs_oracle_seeded():
             continue   # ConvTranspose bias feeding train-mode BN: true gradient is exactly 0 (pure noise)
         err_cpu = float((sd32[name].grad.double() - g64).abs().max()) / scale
         err_gpu = float((p.grad.cpu().double() - g64).abs().max()) / scale
-        if not err_gpu <= 3.0 * err_cpu + 2e-3:
+        if os.environ.get("ADH_TEST_VERBOSE"):
+            l2c = float((sd32[name].grad.double() - g64).norm() / g64.norm())
+            l2g = float((p.grad.cpu().double() - g64).norm() / g64.norm())
+            print(f"VV {algo} {name:44s} max cpu {err_cpu:.2e} gpu {err_gpu:.2e}   l2 cpu {l2c:.2e} gpu {l2g:.2e}")
+        # F(4x4,3x3) in the forward pass: per layer its rounding error is 2.3x the direct kernel's (tools/wino_err.py:
+        # rms 2.3e-7..4.6e-7 of the output scale against 1.0e-7..2.0e-7), which this network turns into up to 8x the
+        # CPU fp32 path's distance from fp64; in the data gradient alone it stays inside the strict bound
+        k_cpu, slack = (10.0, 5e-3) if algo in ("f43", "f43-fwd") else (3.0, 2e-3)
+        if not err_gpu <= k_cpu * err_cpu + slack:
             bad.append((name, err_gpu, err_cpu))
     assert not bad, bad[:8]
     for k, v in m.state_dict().items():
@@ -310,9 +327,11 @@ def test_complex_fullwidth_vs_oracle_seeded():
 @pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 16, 16, 15, 23), (2, 32, 32, 7, 11), (1, 16, 48, 15, 23), (2, 96, 96, 16, 64),
                                            (1, 64, 192, 24, 40), (3, 32, 16, 8, 96), (1, 16, 16, 41, 66),
                                            (1, 32, 64, 24, 96), (1, 96, 96, 40, 160), (1, 48, 32, 40, 128)])   # interior regions
-def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, monkeypatch):
-    """Same layer through conv_wino_kernel and conv_igemm_kernel: outputs and BatchNorm partial statistics agree to
-    fp32 rounding, including ragged regions, channel tails (Co < 32) and the fused residual + ReLU epilogue."""
+@pytest.mark.parametrize("algo", ["f23", "f43"])
+def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, algo, monkeypatch):
+    """Same layer through conv_wino_kernel (F(2x2,3x3)) / conv_wino43_kernel (F(4x4,3x3)) and the direct kernel: outputs
+    and BatchNorm partial statistics agree to fp32 rounding, including ragged regions, channel tails (Co < 32) and the
+    fused residual + ReLU epilogue.  F(4x4,3x3) rounds ~2-3x coarser than the direct kernel."""
     import adam_dehaze_amd.engine as E
     g = torch.Generator().manual_seed(Ci * 31 + Hh)
     x = torch.randn(N, Hh, Ww, Ci, generator=g).to(DEV)
@@ -320,6 +339,8 @@ def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, monkeypatch):
     b = torch.randn(Co, generator=g).to(DEV)
     res = torch.randn(N, Hh, Ww, Co, generator=g).to(DEV)
     got = {}
+    monkeypatch.setattr(E, "USE_WINO43", {"f43": True, "f43-fwd": "fwd", "f43-dgrad": "dgrad"}.get(algo, False))
+    tol = 4e-6 if algo == "f23" else 1.2e-5
     for wino in (False, True):
         monkeypatch.setattr(E, "USE_WINOGRAD", wino)
         eng = Engine(torch.device(DEV), record=False)
@@ -331,8 +352,8 @@ def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, monkeypatch):
         torch.cuda.synchronize()
         got[wino] = (y.cpu(), stats.view(nblk, 2, -1).double().sum(0)[:, :Co].cpu(), y2.cpu())
     scale = float(got[False][0].abs().max())
-    assert max_abs(got[True][0], got[False][0]) < 4e-6 * scale
-    assert max_abs(got[True][2], got[False][2]) < 4e-6 * scale
+    assert max_abs(got[True][0], got[False][0]) < tol * scale
+    assert max_abs(got[True][2], got[False][2]) < tol * scale
     ref_s = got[False][1]
     assert float((got[True][1] - ref_s).abs().max()) < 2e-5 * float(ref_s.abs().max())
 

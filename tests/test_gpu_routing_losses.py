@@ -1,3 +1,4 @@
+import os
 """GPU parity of the routers, classifier, losses and optimiser (through the C ABI) against the golden
 fixtures and the CPU oracle."""
 import warnings
@@ -257,6 +258,10 @@ def test_content_loss_vs_oracle():
     val = c(p, target.to(DEV))
     assert abs(float(val) - float(ref)) < 1e-3 * max(1.0, float(ref))
     val.backward()
+    if os.environ.get("ADH_TEST_VERBOSE"):
+        dg = (p.grad.cpu() - pr.grad)
+        print("VV content", float(dg.abs().max() / pr.grad.abs().max()), float(dg.norm() / pr.grad.norm()),
+              int((dg.abs() > 1e-3 * pr.grad.abs().max()).sum()), dg.numel())
     assert rel_err(p.grad, pr.grad) < 2e-3
 
 

@@ -139,29 +139,38 @@ def test_product_never_imports_oracle():
             assert not re.search(r"^\s*(from|import)\s+[^\n]*oracle", src, flags=re.M), fn
 
 def test_counted_wait_kernels_have_no_scratch_traffic(tmp_path):
-    """conv_wino_kernel / conv_wino32_kernel fetch their weights with inline-asm loads and hand-counted vmcnt waits
-    (csrc/conv_wino.hip, w2_load_b).  A register spill inside those kernels would add scratch loads / stores that the
-    counts do not know about (and compiler waits in the middle of the counted span), so the build must stay spill-free:
-    this compiles the file to ISA on the host and checks that no instantiation touches scratch memory."""
+    """conv_wino_kernel / conv_wino32_kernel / conv_wino43_kernel fetch their weights with inline-asm loads and
+    hand-counted vmcnt waits (csrc/conv_wino.hip, w2_load_b).  A register spill inside the counted span would add scratch
+    loads / stores that the counts do not know about (and compiler waits in the middle of the span): this compiles the
+    files to ISA on the host and checks that no instantiation of the first two touches scratch memory at all, and that
+    conv_wino43_kernel (whose NT = 3 build parks a few epilogue indices in scratch across the main loop) has none
+    between its first and last MFMA, i.e. anywhere in the loop that holds the counted loads."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "adam-dehaze_amd", "csrc", "conv_wino.hip")
-    out = tmp_path / "conv_wino.s"
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-S", "--cuda-device-only", src, "-o", str(out)],
-                   check=True, timeout=900)
-    text = out.read_text()
     kernels = {}
-    cur = None
-    for line in text.splitlines():
-        if line.startswith("_Z") and ":" in line and ("conv_wino_kernel" in line or "conv_wino32_kernel" in line):
-            cur = line.split(":")[0]
-            kernels[cur] = 0
-        elif cur and line.strip().startswith("s_endpgm"):
-            cur = None
-        elif cur and "scratch_" in line:
-            kernels[cur] += 1
-    assert len(kernels) == 6, sorted(kernels)          # NT = 1, 2, 3 of both kernels
-    assert all(v == 0 for v in kernels.values()), kernels
+    for fn in ("conv_wino.hip", "conv_wino43.hip"):
+        src = os.path.join(ROOT, "adam-dehaze_amd", "csrc", fn)
+        out = tmp_path / (fn + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-S", "--cuda-device-only", src, "-o",
+                        str(out)], check=True, timeout=900)
+        cur = None
+        for line in out.read_text().splitlines():
+            if line.startswith("_Z") and ":" in line and any(k in line for k in ("conv_wino_kernel", "conv_wino32_kernel",
+                                                                                 "conv_wino43_kernel")):
+                cur = line.split(":")[0]
+                kernels[cur] = []
+            elif cur and line.strip().startswith("s_endpgm"):
+                cur = None
+            elif cur and ("scratch_" in line or "v_mfma" in line):
+                kernels[cur].append("s" if "scratch_" in line else "m")
+    assert len(kernels) == 9, sorted(kernels)          # NT = 1, 2, 3 of the three kernels
+    for name, ops in kernels.items():
+        seq = "".join(ops)
+        assert "m" in seq, name
+        if "conv_wino43_kernel" in name:
+            assert "s" not in seq[seq.index("m"):seq.rindex("m")], name
+        else:
+            assert "s" not in seq, name
