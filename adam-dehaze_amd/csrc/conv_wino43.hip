@@ -29,7 +29,7 @@
 #include <cstdlib>
 
 #ifndef W4_DBG
-#define W4_DBG 0   // dev builds (-DW4_DBG=n): 1 = skip the input transform, 2 = skip the contraction, 4 = skip the epilogue
+#define W4_DBG 0   // dev builds (-DW4_DBG=n): 1 = skip the input transform, 2 = skip the contraction, 4 = skip the epilogue, 8 = stage only the first chunk
 #endif
 #define W4_KC 16
 #define W4_TILES 32
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         const int cn = more ? c + 1 : c;   // the last chunk re-stages itself (uniform counts)
         // ---- transform raw(c) -> V (every wave is past the previous chunk's contraction: barrier at the loop end)
         // the next chunk's raw tile goes into the other buffer (its last reader was the transform of chunk c - 1)
-        stage_raw(cn, (c + 1) & 1);
+        if (!(W4_DBG & 8)) stage_raw(cn, (c + 1) & 1);
         if (!(W4_DBG & 1)) transform(c & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -274,12 +274,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             // group 0
             w4_load_b<NT>(bv[2], b_voff, b_chunk + 2 * b_fstride);
             av[1] = *reinterpret_cast<const f32x4*>(vlane + 1 * (W4_TILES * W4_KC));
-            w4_wait_b<2 * NT + 10, NT>(bv[0]);
+            w4_wait_b<2 * NT + ((W4_DBG & 8) ? 0 : 10), NT>(bv[0]);
             w4_group<NT, 0, 0, 0>(acc, av[0], bv[0]);
             // group 1
             w4_load_b<NT>(bv[0], b_voff, b_chunk + 3 * b_fstride);
             av[0] = *reinterpret_cast<const f32x4*>(vlane + 2 * (W4_TILES * W4_KC));
-            w4_wait_b<2 * NT + 10, NT>(bv[1]);
+            w4_wait_b<2 * NT + ((W4_DBG & 8) ? 0 : 10), NT>(bv[1]);
             w4_group<NT, 1, 0, 0>(acc, av[1], bv[1]);
             // groups 2..17 (their waits retire the DMA pieces first: in-order return)
             w4_chunk<NT, 2>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, 2 * b_kq);
