@@ -17,20 +17,28 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     __shared__ double red[2][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
-    double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
     if (c < C) {
         int b = ry;
-        for (; b + 32 < nblk; b += 64) {
+        for (; b + 96 < nblk; b += 128) {   // eight independent loads in flight: the loop is latency-bound
             s0 += (double)partials[((size_t)b * 2 + 0) * NcP + c];
             q0 += (double)partials[((size_t)b * 2 + 1) * NcP + c];
             s1 += (double)partials[((size_t)(b + 32) * 2 + 0) * NcP + c];
             q1 += (double)partials[((size_t)(b + 32) * 2 + 1) * NcP + c];
+            s2 += (double)partials[((size_t)(b + 64) * 2 + 0) * NcP + c];
+            q2 += (double)partials[((size_t)(b + 64) * 2 + 1) * NcP + c];
+            s3 += (double)partials[((size_t)(b + 96) * 2 + 0) * NcP + c];
+            q3 += (double)partials[((size_t)(b + 96) * 2 + 1) * NcP + c];
         }
         for (; b < nblk; b += 32) {
             s0 += (double)partials[((size_t)b * 2 + 0) * NcP + c];
             q0 += (double)partials[((size_t)b * 2 + 1) * NcP + c];
         }
     }
+    s0 += s2;
+    s1 += s3;
+    q0 += q2;
+    q1 += q3;
     red[0][ry][cx] = s0 + s1;
     red[1][ry][cx] = q0 + q1;
     __syncthreads();
@@ -239,25 +247,37 @@ extern "C" int adh_bn_bwd_reduce(void* stream, const float* g_out, int g_cs, con
     return adh_check_launch();
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
-                                                              double count, const float* gamma, const float* invstd,
-                                                              float* dgamma, float* dbeta, int accumulate, float* coef) {
-    __shared__ double red[2][8][32];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                               double count, const float* gamma, const float* invstd,
+                                                               float* dgamma, float* dbeta, int accumulate, float* coef) {
+    // 32 channels x 32 row slices per block, four independent fp64 chains per thread (latency-bound loop)
+    __shared__ double red[2][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
-    double s = 0.0, q = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
     if (c < C) {
-        for (int b = ry; b < nblk; b += 8) {
-            s += (double)partials[((size_t)b * 2 + 0) * C + c];
-            q += (double)partials[((size_t)b * 2 + 1) * C + c];
+        int b = ry;
+        for (; b + 96 < nblk; b += 128) {
+            s0 += (double)partials[((size_t)b * 2 + 0) * C + c];
+            q0 += (double)partials[((size_t)b * 2 + 1) * C + c];
+            s1 += (double)partials[((size_t)(b + 32) * 2 + 0) * C + c];
+            q1 += (double)partials[((size_t)(b + 32) * 2 + 1) * C + c];
+            s2 += (double)partials[((size_t)(b + 64) * 2 + 0) * C + c];
+            q2 += (double)partials[((size_t)(b + 64) * 2 + 1) * C + c];
+            s3 += (double)partials[((size_t)(b + 96) * 2 + 0) * C + c];
+            q3 += (double)partials[((size_t)(b + 96) * 2 + 1) * C + c];
+        }
+        for (; b < nblk; b += 32) {
+            s0 += (double)partials[((size_t)b * 2 + 0) * C + c];
+            q0 += (double)partials[((size_t)b * 2 + 1) * C + c];
         }
     }
-    red[0][ry][cx] = s;
-    red[1][ry][cx] = q;
+    red[0][ry][cx] = (s0 + s1) + (s2 + s3);
+    red[1][ry][cx] = (q0 + q1) + (q2 + q3);
     __syncthreads();
     if (ry == 0 && c < C) {
         double S = 0.0, Q = 0.0;
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 32; ++r) {
             S += red[0][r][cx];
             Q += red[1][r][cx];
         }
@@ -273,7 +293,7 @@ extern "C" int adh_bn_bwd_finalize(void* stream, const float* partials, int nblk
                                    const float* gamma, const float* invstd, float* dgamma, float* dbeta, int accumulate,
                                    float* coef) {
     if (!partials || !invstd || !coef || nblk < 1 || C < 1 || count <= 0) return ADH_E_ARG;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(adh_ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partials,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(adh_ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)stream, partials,
                        nblk, C, count, gamma, invstd, dgamma, dbeta, accumulate, coef);
     return adh_check_launch();
 }

@@ -740,16 +740,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     w2_wait_b<0, NT>(bv[0]);
 
     // ---------------------------------------------------------------------- output transform G^T M G + fused epilogue
-    float* M = lds;   // [16][64][32]: spans V and the raw buffers
-    const int cl = tid & 31;
+    // One 32-channel tile at a time: accumulators -> M[16][64 tile rows][32 co] in LDS (tile t sits in row t' = t with its
+    // low three bits rotated, so the two lane halves -- tiles t and t + 4 -- hit different banks), then thread = (tile,
+    // channel quad), two tiles each: float4 reads of the 4x4 frequency patch, G^T m G, fused epilogue, 16-byte stores.
+    float* M = lds;   // spans V and the raw buffers
+    const int eq = tid & 7;
     float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
     const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
-    const bool full = vy0 + 12 <= d.VH && vx0 + 48 <= d.VW && co0 + 32 * NT <= d.Cout;
-    const int ocs = d.out_cstride * 4, rcs = d.res_cstride * 4;
-    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(out_n, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr_ =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res_n ? res_n : d.in), 0, 0x7fffffff, 0x00020000);
-    const int ovoff = 3 * (tid >> 5) * d.out_sx * ocs + cl * 4, rvoff = 3 * (tid >> 5) * d.out_sx * rcs + cl * 4;
+    const bool vec_ok = (d.out_cstride & 3) == 0 && ((uintptr_t)d.out & 15) == 0 &&
+                        (!d.residual || ((d.res_cstride & 3) == 0 && ((uintptr_t)d.residual & 15) == 0));
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         __builtin_amdgcn_s_barrier();   // V / raw (first tile) or the previous tile's M fully consumed
@@ -759,105 +758,92 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
             for (int th = 0; th < 2; ++th)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int t = (r & 3) + 8 * (r >> 2) + 4 * h + 32 * th;
-                    M[((wave * 4 + f) * W2_TILES + t) * 32 + l31] = acc[(f * 2 + th) * NT + j][r];
+                    const int tp = 8 * (r >> 2) + ((r & 3) << 1) + h + 32 * th;   // row of tile (r&3) + 8*(r>>2) + 4*h + 32*th
+                    M[((wave * 4 + f) * W2_TILES + tp) * 32 + l31] = acc[(f * 2 + th) * NT + j][r];
                 }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int co = co0 + j * 32 + cl;
-        const bool cvalid = co < d.Cout;
-        const float sc = (d.scale && cvalid) ? d.scale[co] : 1.f;
-        const float sh = (d.shift && cvalid) ? d.shift[co] : 0.f;
-        float ssum = 0.f, ssq = 0.f;
-        // y[3][3] = G^T M G of tile t for channel cl
-        auto out_tile = [&](int t, float (&y)[3][3]) {
-            float m[16];
+        const int cq0 = co0 + j * 32 + eq * 4;
+        f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int f = 0; f < 16; ++f) m[f] = M[(f * W2_TILES + t) * 32 + cl];
-            float u[3][4];
+        for (int e = 0; e < 4; ++e) {
+            if (d.scale && cq0 + e < d.Cout) sc4[e] = d.scale[cq0 + e];
+            if (d.shift && cq0 + e < d.Cout) sh4[e] = d.shift[cq0 + e];
+        }
+        const bool vec = vec_ok && cq0 + 3 < d.Cout;
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float hs = 0.5f * (m[1 * 4 + b] + m[2 * 4 + b]), hd = 0.5f * (m[1 * 4 + b] - m[2 * 4 + b]);
-                u[0][b] = m[0 * 4 + b] + hs;
-                u[1][b] = hd;
-                u[2][b] = hs + m[3 * 4 + b];
+        for (int p = 0; p < 2; ++p) {
+            const int t = (tid >> 3) + 32 * p;                       // tile: row t >> 4, column t & 15
+            const int tp = (t & ~7) | ((t & 3) << 1) | ((t >> 2) & 1);
+            const float* mp = M + tp * 32 + eq * 4;
+            // u[i][b] = sum_a G^T[i][a] m[a][b],  G^T = [[1, 1/2, 1/2, 0], [0, 1/2, -1/2, 0], [0, 1/2, 1/2, 1]]
+            f32x4 u[3][4];
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) {
+                f32x4 m[4];
+#pragma unroll
+                for (int a2 = 0; a2 < 4; ++a2) m[a2] = *reinterpret_cast<const f32x4*>(mp + (a2 * 4 + b2) * (W2_TILES * 32));
+                const f32x4 hs = 0.5f * (m[1] + m[2]), hd = 0.5f * (m[1] - m[2]);
+                u[0][b2] = m[0] + hs;
+                u[1][b2] = hd;
+                u[2][b2] = hs + m[3];
             }
+            const int vyb = vy0 + 3 * (t >> 4), vxb = vx0 + 3 * (t & 15);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float hs = 0.5f * (u[i][1] + u[i][2]), hd = 0.5f * (u[i][1] - u[i][2]);
-                y[i][0] = u[i][0] + hs;
-                y[i][1] = hd;
-                y[i][2] = hs + u[i][3];
-            }
-        };
-        if (full) {
-            // whole region inside the virtual grid, all 32 channels real: no predicates; every global address is the
-            // per-thread constant voffset plus a scalar offset
-            const int cbytes = (co0 + j * 32) * 4;
-            auto opix = [&](int p, int i, int jj) {
-                return ((vy0 + 3 * (p >> 1) + i) * d.out_sy + d.out_oy) * d.OW + (vx0 + 24 * (p & 1) + jj) * d.out_sx + d.out_ox;
-            };
-#pragma unroll 2
-            for (int p = 0; p < 8; ++p) {
-                float y[3][3];
-                out_tile((tid >> 5) + 8 * p, y);
-                float rv[3][3];
-                if (res_n) {
+                const f32x4 hs = 0.5f * (u[i][1] + u[i][2]), hd = 0.5f * (u[i][1] - u[i][2]);
+                const f32x4 y[3] = {u[i][0] + hs, hd, hs + u[i][3]};
+                const int vy = vyb + i;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < 3; ++jj)
-                            rv[i][jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr_, rvoff, opix(p, i, jj) * rcs + cbytes, 0));
-                }
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) {
-                        float v = y[i][jj] * sc + sh;
+                for (int jj = 0; jj < 3; ++jj) {
+                    const int vx = vxb + jj;
+                    if (vy < d.VH && vx < d.VW) {
+                        f32x4 v = y[jj] * sc4 + sh4;
                         ssum += v;
                         ssq += v * v;
-                        if (res_n) v += rv[i][jj];
-                        if (d.act == ADH_ACT_RELU) v = fmaxf(v, 0.f);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), or_, ovoff, opix(p, i, jj) * ocs + cbytes, 0);
-                    }
-            }
-        } else {
-#pragma unroll 1
-            for (int p = 0; p < 8; ++p) {
-                const int t = (tid >> 5) + 8 * p;
-                const int trow = t >> 4, tc = t & 15;
-                float y[3][3];
-                out_tile(t, y);
+                        const size_t pix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
+                        if (vec) {
+                            if (res_n) v += *reinterpret_cast<const f32x4*>(res_n + pix * d.res_cstride + cq0);
+                            if (d.act == ADH_ACT_RELU)
+                                v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                            *reinterpret_cast<f32x4*>(out_n + pix * d.out_cstride + cq0) = v;
+                        } else {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int vy = vy0 + 3 * trow + i;
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) {
-                        const int vx = vx0 + 3 * tc + jj;
-                        if (cvalid && vy < d.VH && vx < d.VW) {
-                            float v = y[i][jj] * sc + sh;
-                            ssum += v;
-                            ssq += v * v;
-                            const size_t pix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
-                            if (res_n) v += res_n[pix * d.res_cstride + co];
-                            if (d.act == ADH_ACT_RELU) v = fmaxf(v, 0.f);
-                            out_n[pix * d.out_cstride + co] = v;
+                            for (int e = 0; e < 4; ++e)
+                                if (cq0 + e < d.Cout) {
+                                    float ve = v[e];
+                                    if (res_n) ve += res_n[pix * d.res_cstride + cq0 + e];
+                                    if (d.act == ADH_ACT_RELU) ve = fmaxf(ve, 0.f);
+                                    out_n[pix * d.out_cstride + cq0 + e] = ve;
+                                }
                         }
                     }
                 }
             }
         }
         if (d.stats) {
+            // sum over the 8 tiles of this wave (lane bits 3..5), then over the 4 waves through LDS
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    ssum[e] += __shfl_xor(ssum[e], o, 64);
+                    ssq[e] += __shfl_xor(ssq[e], o, 64);
+                }
+            }
             if (j) __builtin_amdgcn_s_barrier();
-            red[(0 * 8 + (tid >> 5)) * 32 + cl] = ssum;
-            red[(1 * 8 + (tid >> 5)) * 32 + cl] = ssq;
+            if (lane < 8) {
+                *reinterpret_cast<f32x4*>(red + (0 * 4 + wave) * 32 + eq * 4) = ssum;
+                *reinterpret_cast<f32x4*>(red + (1 * 4 + wave) * 32 + eq * 4) = ssq;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tid < 64) {
-                const int which = tid >> 5;
+                const int which = tid >> 5, cl = tid & 31;
                 float v = 0.f;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v += red[(which * 8 + r) * 32 + cl];
+                for (int r = 0; r < 4; ++r) v += red[(which * 4 + r) * 32 + cl];
                 d.stats[((size_t)region * 2 + which) * d.NcP + co0 + j * 32 + cl] = v;
             }
         }
