@@ -92,17 +92,24 @@ __device__ __forceinline__ void w4_wait_b(f32x4 (&b)[NT]) {
 // LDS (dst + a * stride floats) as soon as they exist.  Rows of B^T = coefficients of prod_{q != p} (x - q):
 //   p = 0:    a^2 b^2 d0 - (a^2 + b^2) d2 + d4          p = +-a:  (d4 - b^2 d2) +- a (d3 - b^2 d1)
 //   p = inf:  a^2 b^2 d1 - (a^2 + b^2) d3 + d5          p = +-b:  (d4 - a^2 d2) +- b (d3 - a^2 d1)
-__device__ __forceinline__ void w4_bt_store(f32x4 (&d)[6], float* dst, int stride) {
-    d[0] = W4_A2B2 * d[0] + (d[4] - W4_S2 * d[2]);
+struct W4Neg { float s2, b2, a2, a, b; };   // -(a^2+b^2), -b^2, -a^2, -a, -b held in SGPRs the compiler cannot see through:
+// it would otherwise rewrite `(-c) * x + y` as fma(-x, c, y) and spend a v_xor per register on the sign
+__device__ __forceinline__ W4Neg w4_neg_constants() {
+    W4Neg n = {-W4_S2, -W4_B2, -W4_A2, -W4_A, -W4_B};
+    asm volatile("" : "+s"(n.s2), "+s"(n.b2), "+s"(n.a2), "+s"(n.a), "+s"(n.b));
+    return n;
+}
+__device__ __forceinline__ void w4_bt_store(f32x4 (&d)[6], float* dst, int stride, const W4Neg& n) {
+    d[0] = W4_A2B2 * d[0] + (n.s2 * d[2] + d[4]);
     *reinterpret_cast<f32x4*>(dst) = d[0];
-    d[5] = W4_A2B2 * d[1] + (d[5] - W4_S2 * d[3]);
+    d[5] = W4_A2B2 * d[1] + (n.s2 * d[3] + d[5]);
     *reinterpret_cast<f32x4*>(dst + 5 * stride) = d[5];
-    const f32x4 p = d[4] - W4_B2 * d[2], r = d[4] - W4_A2 * d[2];
-    const f32x4 q = d[3] - W4_B2 * d[1], s = d[3] - W4_A2 * d[1];
-    *reinterpret_cast<f32x4*>(dst + 1 * stride) = p + W4_A * q;
-    *reinterpret_cast<f32x4*>(dst + 2 * stride) = p - W4_A * q;
-    *reinterpret_cast<f32x4*>(dst + 3 * stride) = r + W4_B * s;
-    *reinterpret_cast<f32x4*>(dst + 4 * stride) = r - W4_B * s;
+    const f32x4 p = n.b2 * d[2] + d[4], r = n.a2 * d[2] + d[4];
+    const f32x4 q = n.b2 * d[1] + d[3], s = n.a2 * d[1] + d[3];
+    *reinterpret_cast<f32x4*>(dst + 1 * stride) = W4_A * q + p;
+    *reinterpret_cast<f32x4*>(dst + 2 * stride) = n.a * q + p;
+    *reinterpret_cast<f32x4*>(dst + 3 * stride) = W4_B * s + r;
+    *reinterpret_cast<f32x4*>(dst + 4 * stride) = n.b * s + r;
 }
 
 // runs the 18 groups of one chunk; GI = group index (frequency GI % 9, channel half GI / 9)
@@ -173,12 +180,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     auto stage_raw = [&](int c, int buf) {
         const int cb = c * (W4_KC * 4);
         const int lo = __builtin_amdgcn_readfirstlane((W4_VF + buf * W4_RAWF + wave * 256) * 4);
+        int vo[10];   // all table reads first: one LDS round trip instead of ten
 #pragma unroll
-        for (int u = 0; u < 10; ++u) {
-            const int vo = tab_lane[64 * u] + cq_l * 16;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + lo + u * 4096), 16, vo,
-                                                     cb, 0, 0);
-        }
+        for (int u = 0; u < 10; ++u) vo[u] = tab_lane[64 * u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 10; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + lo + u * 4096), 16,
+                                                     vo[u] + cq_l * 16, cb, 0, 0);
     };
     auto fix_raw = [&](int buf) {
         if (interior) return;
@@ -201,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         const int cs = k == 0 ? (csel ? 9 : 0) : (k == 1 ? (csel ? 26 : 18) : (csel ? 10 : 1));
         return rbase_t + (i * W4_ROWSLOTS + cs) * 16;
     };
+    const W4Neg negc = w4_neg_constants();
     auto transform = [&](int buf) {
         const float* raw = rawbase + buf * W4_RAWF;
         // pass 1: T[a][c] = sum_i B^T[a][i] d[i][c] for this thread's three columns c = csel, 2 + csel, 4 + csel
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             f32x4 dd[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) dd[i] = *reinterpret_cast<const f32x4*>(raw + raw_off(i, k));
-            w4_bt_store(dd, lds + c * (W4_TILES * W4_KC) + vslot_t, 6 * W4_TILES * W4_KC);
+            w4_bt_store(dd, lds + c * (W4_TILES * W4_KC) + vslot_t, 6 * W4_TILES * W4_KC, negc);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             f32x4 tt[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) tt[c] = *reinterpret_cast<const f32x4*>(lds + (a * 6 + c) * (W4_TILES * W4_KC) + vslot_t);
-            w4_bt_store(tt, lds + (a * 6) * (W4_TILES * W4_KC) + vslot_t, W4_TILES * W4_KC);
+            w4_bt_store(tt, lds + (a * 6) * (W4_TILES * W4_KC) + vslot_t, W4_TILES * W4_KC, negc);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
