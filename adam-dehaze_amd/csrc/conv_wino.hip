@@ -686,24 +686,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
 
 #pragma unroll 1
     for (int s = 0; s < nslabs; ++s) {
-        // raw(s+1) sits in buffer (s+1)&1 (landed and fixed); raw(s+2) goes into buffer s&1, free since transform(s)
+        // raw(s+1) sits in buffer (s+1)&1; raw(s+2) is staged into buffer s&1 (free since transform(s)) from the LAST group
+        // of this slab: vmcnt returns in order, so every weight wait behind the DMA also waits for the DMA -- issued there,
+        // the pieces have the last group, the transform and the next slab's first group (whose weights are already in
+        // flight) to land, instead of two groups
         const int s2 = s + 2 < nslabs ? s + 2 : s;     // the last two slabs re-issue an earlier tile: uniform counts
         const int sn = s + 1 < nslabs ? s + 1 : s;
         load_a(0, 0, av[0]);
         w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 1, 0));
-        stage_raw(s2, s & 1);
         load_a(1, 0, av[1]);
-        w2_wait_b<NT + 10, NT>(bv[0]);
+        w2_wait_b<NT + 10, NT>(bv[0]);       // (the previous slab's 10 raw pieces may still be in flight)
         w2_group<NT, 0, 0, 0, 0>(acc, av[0], bv[0]);
 
         w2_load_b<NT>(bv[0], b_voff, b_ptr(s, 2, 0));
         load_a(2, 0, av[0]);
-        w2_wait_b<NT + 10, NT>(bv[1]);
+        w2_wait_b<NT, NT>(bv[1]);            // also retires those raw pieces (in-order return)
         w2_group<NT, 1, 0, 0, 0>(acc, av[1], bv[1]);
 
         w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 3, 0));
         load_a(3, 0, av[1]);
-        w2_wait_b<NT, NT>(bv[0]);            // also retires this wave's 10 raw pieces (in-order return)
+        w2_wait_b<NT, NT>(bv[0]);
         w2_group<NT, 2, 0, 0, 0>(acc, av[0], bv[0]);
 
         w2_load_b<NT>(bv[0], b_voff, b_ptr(s, 0, 1));
@@ -727,10 +729,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
         w2_group<NT, 2, 0, 0, 0>(acc, av[0], bv[0]);
 
         w2_load_b<NT>(bv[0], b_voff, b_ptr(sn, 0, 0));
-        w2_wait_b<NT, NT>(bv[1]);
+        stage_raw(s2, s & 1);
+        w2_wait_b<NT + 10, NT>(bv[1]);
         w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
-        // ---- V is free once every wave is here; the tile staged during this slab has landed (third wait above)
-        fix_raw(s2, s & 1);
+        // ---- V is free once every wave is here; raw(s+1) landed during this slab (second wait above)
+        fix_raw(sn, (s + 1) & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         transform((s + 1) & 1);              // (after the last slab: a harmless re-transform, keeps the span branch-free)
