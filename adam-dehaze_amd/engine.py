@@ -24,6 +24,9 @@ BN_MOMENTUM = 0.1
 USE_WINOGRAD = os.environ.get("ADH_WINOGRAD", "1") != "0"
 # F(4x4,3x3) where it applies, else F(2x2,3x3): True / False, or "fwd" / "dgrad" to restrict it to one direction
 USE_WINO43 = {"0": False, "1": True}.get(os.environ.get("ADH_WINO43", "1"), os.environ.get("ADH_WINO43", "1"))
+# F(4x4,3x3)-domain weight gradient (conv_wgrad43.hip): correct and tested, but 15-25 % slower than the F(2x2,3x3)-domain
+# kernel as of round 1 -- opt-in
+USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "0") != "0"
 _WINO_ONLY = os.environ.get("ADH_WINOGRAD_ONLY", "")   # dev: "fwd" or "dgrad" restricts the Winograd path to one direction
 
 
@@ -380,6 +383,18 @@ class Engine:
             groups = (KP // 32) * max(1, NcP // 96) * zgroups
             # one 512-thread workgroup per CU is resident: aim at ~4 rounds of 256 workgroups
             T = gm["KH"] * gm["KW"]
+            w43_groups = H.value("adh_conv_wgrad_wino43_groups", C.byref(d)) if (USE_WINOGRAD and USE_WINO43_WGRAD) else 0
+            if w43_groups:
+                # 3x3 stride-1, channels in multiples of 96: accumulate in the F(4x4,3x3) domain (36 frequency slabs)
+                nstrips = x.N * (VH // 4) * ((VW // 4 + 5) // 6)
+                nsplit = _rows_nsplit(w43_groups, nstrips)
+                while nsplit * 36 * KP * NcP * 4 > (1 << 30) and nsplit > 1:
+                    nsplit //= 2
+                slab = self._f(nsplit * 36 * KP * NcP)
+                H.call("adh_conv_wgrad_wino43", C.byref(d), slab.data_ptr(), nsplit,
+                       work=2.0 * d.N * d.VH * d.VW * T * L.K * L.Nc, work_exec=2.0 * d.N * d.VH * d.VW * 2.25 * L.K * L.Nc)
+                H.call("adh_wgrad_reduce_wino43", slab.data_ptr(), nsplit, KP, NcP, C.byref(L), dw.data_ptr(), 0)
+                continue
             wino_groups = H.value("adh_conv_wgrad_wino_groups", C.byref(d)) if USE_WINOGRAD else 0
             if wino_groups:
                 # 3x3 stride-1: accumulate in the Winograd domain (16 frequency slabs), G^T(.)G in the reduce

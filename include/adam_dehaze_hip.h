@@ -119,6 +119,17 @@ int adh_conv_wino43_supported(const adh_conv_desc* d);
 int adh_conv_wino43_num_blocks(const adh_conv_desc* d);
 int adh_conv_wino43_forward(void* stream, const adh_conv_desc* d);
 int adh_pack_weights_wino43(void* stream, const float* src, const adh_wlayout* L, float* wp);
+
+/* Weight gradient of the same layers in the F(4x4,3x3) Winograd domain (conv_wgrad43.hip): 1/4 of the direct MFMA
+ * work.  Needs Cin % 96 == 0, Cout % 96 == 0, H % 4 == 0, W % 4 == 0 (adh_conv_wgrad_wino43_groups(d) > 0: its value is
+ * the number of workgroups per pixel split of each of the three launches, one per frequency-row pair).  d->in = x,
+ * d->out = dL/dy as for adh_conv_wgrad.  slab: nsplit * 36 * Cin * NcP floats; adh_wgrad_reduce_wino43 sums the splits
+ * (in place) and applies A'^T (.) A' with the 1/(N_a N_b) normalisation in double.  Replaces the weight half of ATen's
+ * conv2d backward (/root/reference models/dehazing/base_model.py:11-13). */
+int adh_conv_wgrad_wino43_groups(const adh_conv_desc* d);
+int adh_conv_wgrad_wino43(void* stream, const adh_conv_desc* d, float* slab, int nsplit);
+int adh_wgrad_reduce_wino43(void* stream, float* slab, int nsplit, int KP, int NcP, const adh_wlayout* L, float* dst,
+                            int accumulate);
 /* weight gradient of the gather form: slab[s][tap][KP][NcP] partial sums over `nsplit` pixel
  * ranges (KP = Cin rounded up to 32); d->out is the gradient wrt the conv output. */
 int adh_conv_wgrad(void* stream, const adh_conv_desc* d, float* slab, int nsplit);

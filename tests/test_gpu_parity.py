@@ -364,10 +364,15 @@ def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, algo, monkeypatch):
 
 @pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 96, 96, 12, 64), (1, 32, 64, 24, 96), (3, 64, 32, 8, 32), (1, 192, 96, 16, 64),
                                            (2, 96, 48, 16, 64),     # partial last n-tile (output_conv.1 of the headline model)
-                                           (1, 32, 16, 8, 32)])
-def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, monkeypatch):
-    """conv_wgrad_rows_kernel in Winograd mode + adh_wgrad_reduce_wino against the direct row-split kernel and the
-    fp64 definition, on tiles with and without image borders."""
+                                           (1, 32, 16, 8, 32),
+                                           (1, 96, 96, 4, 8), (2, 96, 192, 8, 24), (1, 192, 192, 12, 100),   # strips: ragged,
+                                           (1, 96, 96, 40, 200), (3, 96, 96, 16, 48)])                        # interior, exact
+@pytest.mark.parametrize("algo", ["f23", "f43"])
+def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, algo, monkeypatch):
+    """Winograd-domain weight gradients -- conv_wgrad_rows_kernel in Winograd mode + adh_wgrad_reduce_wino (F(2x2,3x3)
+    domain) and conv_wgrad_wino43_kernel + adh_wgrad_reduce_wino43 (F(4x4,3x3) domain; channel counts in multiples of 96,
+    other shapes fall through to the former) -- against the direct row-split kernel and the fp64 definition, on tiles
+    and strips with and without image borders."""
     import adam_dehaze_amd.engine as E
     g = torch.Generator().manual_seed(Ci + 7 * Hh)
     x = torch.randn(N, Hh, Ww, Ci, generator=g)
@@ -376,6 +381,7 @@ def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, monkeypatch)
     ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Co, Ci, 3, 3), gy.permute(0, 3, 1, 2).double(),
                                       stride=1, padding=1)
     got = {}
+    monkeypatch.setattr(E, "USE_WINO43_WGRAD", algo == "f43")
     for wino in (False, True):
         monkeypatch.setattr(E, "USE_WINOGRAD", wino)
         eng = Engine(torch.device(DEV), record=False)
