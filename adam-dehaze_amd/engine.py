@@ -27,6 +27,7 @@ USE_WINO43 = {"0": False, "1": True}.get(os.environ.get("ADH_WINO43", "1"), os.e
 # F(4x4,3x3)-domain weight gradient (conv_wgrad43.hip): correct and tested, but 15-25 % slower than the F(2x2,3x3)-domain
 # kernel as of round 1 -- opt-in
 USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "0") != "0"
+USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"      # conv_wgrad_small.hip for the few-channel 3x3 layers
 _WINO_ONLY = os.environ.get("ADH_WINOGRAD_ONLY", "")   # dev: "fwd" or "dgrad" restricts the Winograd path to one direction
 
 
@@ -383,6 +384,14 @@ class Engine:
             groups = (KP // 32) * max(1, NcP // 96) * zgroups
             # one 512-thread workgroup per CU is resident: aim at ~4 rounds of 256 workgroups
             T = gm["KH"] * gm["KW"]
+            small = H.value("adh_conv_wgrad_small_slabs", C.byref(d)) if USE_SMALL_WGRAD else 0
+            if small:
+                # 3x3 stride-1 with few channels (guidance branch, output convolution): 16x16x4 MFMA tiles
+                slab = self._f(small * 9 * KP * NcP)
+                H.call("adh_conv_wgrad_small", C.byref(d), slab.data_ptr(), KP, NcP,
+                       work=2.0 * d.N * d.VH * d.VW * T * L.K * L.Nc)
+                H.call("adh_wgrad_reduce_small", slab.data_ptr(), small, KP, NcP, C.byref(L), dw.data_ptr(), 0)
+                continue
             w43_groups = H.value("adh_conv_wgrad_wino43_groups", C.byref(d)) if (USE_WINOGRAD and USE_WINO43_WGRAD) else 0
             if w43_groups:
                 # 3x3 stride-1, channels in multiples of 96: accumulate in the F(4x4,3x3) domain (36 frequency slabs)

@@ -120,6 +120,16 @@ int adh_conv_wino43_num_blocks(const adh_conv_desc* d);
 int adh_conv_wino43_forward(void* stream, const adh_conv_desc* d);
 int adh_pack_weights_wino43(void* stream, const float* src, const adh_wlayout* L, float* wp);
 
+/* Weight gradient of the 3x3 s1 p1 convolutions with few channels (conv_wgrad_small.hip, MFMA 16x16x4: one tile = one tap
+ * x 16 input channels x up to 16 output channels): channel strides (in, out) = (8, 16), (16, 16) or (48, 8), Cout <= 16 --
+ * the guidance branch and the output convolution of the Complex model
+ * (/root/reference models/dehazing/high_intensity.py:74-90).  adh_conv_wgrad_small_slabs(d) = number of slabs
+ * [9][KP][NcP] the launch writes (0: not one of its shapes); adh_wgrad_reduce_small adds them (one wave per element). */
+int adh_conv_wgrad_small_slabs(const adh_conv_desc* d);
+int adh_conv_wgrad_small(void* stream, const adh_conv_desc* d, float* slab, int KP, int NcP);
+int adh_wgrad_reduce_small(void* stream, const float* slab, int nslabs, int KP, int NcP, const adh_wlayout* L, float* dst,
+                           int accumulate);
+
 /* Weight gradient of the same layers in the F(4x4,3x3) Winograd domain (conv_wgrad43.hip): 1/4 of the direct MFMA
  * work.  Needs Cin % 96 == 0, Cout % 96 == 0, H % 4 == 0, W % 4 == 0 (adh_conv_wgrad_wino43_groups(d) > 0: its value is
  * the number of workgroups per pixel split of each of the three launches, one per frequency-row pair).  d->in = x,

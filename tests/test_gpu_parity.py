@@ -391,6 +391,33 @@ def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, algo, monkey
     assert float((got[False] - ref).abs().max()) < 2e-5 * scale
     assert float((got[True] - ref).abs().max()) < 2e-5 * scale
 
+@pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 3, 16, 13, 70), (1, 16, 16, 8, 64), (2, 16, 16, 21, 130), (1, 48, 3, 12, 64),
+                                           (2, 48, 3, 9, 75), (1, 3, 16, 4, 5)])
+def test_small_channel_weight_gradient(N, Ci, Co, Hh, Ww, monkeypatch):
+    """conv_wgrad_small_kernel (MFMA 16x16x4; the guidance branch 3 -> 16 -> 16 and the output convolution 48 -> 3)
+    against the general kernel and the fp64 definition, with ragged tiles; the input of the 3-channel case is the NHWC8
+    image layout and the 3-channel output gradient is stored with 8 channels, as the engine does."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(Ci * 5 + Hh)
+    Ca, Ga = (Ci + 7) // 8 * 8, (Co + 7) // 8 * 8
+    x = torch.zeros(N, Hh, Ww, Ca)
+    x[..., :Ci] = torch.randn(N, Hh, Ww, Ci, generator=g)
+    gy = torch.zeros(N, Hh, Ww, Ga)
+    gy[..., :Co] = torch.randn(N, Hh, Ww, Co, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3, device=DEV, requires_grad=True)
+    ref = torch.nn.grad.conv2d_weight(x[..., :Ci].permute(0, 3, 1, 2).double(), (Co, Ci, 3, 3),
+                                      gy[..., :Co].permute(0, 3, 1, 2).double(), stride=1, padding=1)
+    got = {}
+    for small in (False, True):
+        monkeypatch.setattr(E, "USE_SMALL_WGRAD", small)
+        eng = Engine(torch.device(DEV), record=False)
+        plans = eng._launch_plan("conv", 3, 1, 1, w, "fwd")
+        got[small] = eng._wgrad(plans, Act(x.to(DEV), Ci), gy.to(DEV), Co, w).cpu().double()
+    scale = float(ref.abs().max())
+    assert float((got[False] - ref).abs().max()) < 2e-5 * scale
+    assert float((got[True] - ref).abs().max()) < 2e-5 * scale
+
+
 @pytest.mark.parametrize("kind,N,Ci,Co,Hh,Ww", [("conv", 1, 32, 96, 48, 96), ("conv", 2, 16, 64, 26, 50), ("conv", 1, 96, 192, 24, 192),
                                                 ("convT", 1, 64, 96, 12, 48), ("convT", 2, 32, 32, 13, 25), ("convT", 1, 16, 192, 24, 96)])
 def test_winograd32_matches_direct_path(kind, N, Ci, Co, Hh, Ww, monkeypatch):
