@@ -324,6 +324,11 @@ class Engine:
                 else:
                     d.dy0 = d.dx0 = gm["dy0"]
                     d.dstep_y = d.dstep_x = gm["dstep"]
+            if not wino and gm["KH"] == 7 and L.K <= 3 and residual is None and USE_SMALL_WGRAD and \
+                    H.value("adh_conv_stem_num_blocks", C.byref(d)):
+                wino = "stem"   # 7x7 stem on the NHWC8 image: (kx, c)-packed 16x16x4 tiles (conv_stem.hip)
+                wp = self._f(7 * 24 * NcP)
+                H.call("adh_pack_weights_stem", w.data_ptr(), C.byref(L), wp.data_ptr())
             if not wino:
                 wp = self._pack(w, L)   # keep alive until the launch below is enqueued
             d.wp = wp.data_ptr()
@@ -334,7 +339,7 @@ class Engine:
                 d.res_cstride = residual.stride(2)
             d.act = act
             nb = H.value({32: "adh_conv_wino32_num_blocks", 43: "adh_conv_wino43_num_blocks", True: "adh_conv_wino_num_blocks",
-                          False: "adh_conv_num_blocks"}[wino], C.byref(d))
+                          "stem": "adh_conv_stem_num_blocks", False: "adh_conv_num_blocks"}[wino], C.byref(d))
             descs.append((d, nb, wp, wino))
             total_blocks += nb
         stats = None
@@ -349,7 +354,9 @@ class Engine:
                 d.stats = stats.data_ptr() + row * 2 * d.NcP * 4
             # algorithmic FLOPs of this launch: 2 * virtual pixels * taps * real K * real Nc (Winograd executes 4/9)
             work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
-            if wino == 43:
+            if wino == "stem":
+                H.call("adh_conv_stem_forward", C.byref(d), work=work)
+            elif wino == 43:
                 H.call("adh_conv_wino43_forward", C.byref(d), work=work, work_exec=work * 0.25)
             elif wino == 32:
                 H.call("adh_conv_wino32_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
@@ -366,7 +373,20 @@ class Engine:
         dw = self._f(*w.shape)
         if x.C == 8 and x.cs == 8 and w.dim() == 4 and w.shape[1] <= 8 and w.shape[2] == 7 and len(plans) == 1 \
                 and plans[0][1]["in_s"] == 1:
-            return self._wgrad_packed_stem(plans[0][1], x, g_y, gC, w, dw)
+            gm = plans[0][1]
+            if USE_SMALL_WGRAD and w.shape[1] <= 3:
+                L = plans[0][0]
+                NcP = _round_up(L.Nc, 32)
+                VH, VW = g_y.shape[1], g_y.shape[2]
+                d = self._conv_desc(x, 4, g_y, _round_up(gC, 4), NcP, VH, VW, 7, 7, 1, 1, (0, 0), gm["dy0"], gm["dx0"], 1)
+                nslabs = H.value("adh_conv_wgrad_stem_slabs", C.byref(d))
+                if nslabs:   # (kx, c)-packed 16x16x4 tiles (conv_stem.hip)
+                    slab = self._f(nslabs * 49 * 8 * NcP)
+                    H.call("adh_conv_wgrad_stem", C.byref(d), slab.data_ptr(), NcP,
+                           work=2.0 * d.N * VH * VW * 49 * L.K * L.Nc)
+                    H.call("adh_wgrad_reduce_small", slab.data_ptr(), nslabs, 8, NcP, C.byref(L), dw.data_ptr(), 0)
+                    return dw
+            return self._wgrad_packed_stem(gm, x, g_y, gC, w, dw)
         for L, gm in plans:
             NcP = _round_up(L.Nc, 32)
             KP = _round_up(L.K, 32)

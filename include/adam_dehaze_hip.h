@@ -130,6 +130,21 @@ int adh_conv_wgrad_small(void* stream, const adh_conv_desc* d, float* slab, int 
 int adh_wgrad_reduce_small(void* stream, const float* slab, int nslabs, int KP, int NcP, const adh_wlayout* L, float* dst,
                            int accumulate);
 
+/* Forward of the 7x7 s1 p3 stem (3 -> 64 / 96 channels on the NHWC8 image; conv_stem.hip): same descriptor and fused
+ * epilogue as adh_conv_forward (scale / shift, ReLU, BatchNorm partial statistics; no residual), weights packed by
+ * adh_pack_weights_stem -> [7][24][NcP] floats.  Statistics rows = adh_conv_stem_num_blocks(d) (0: not the stem).
+ * Replaces ATen's conv2d for init_conv (/root/reference models/dehazing/high_intensity.py:24). */
+int adh_conv_stem_num_blocks(const adh_conv_desc* d);
+int adh_conv_stem_forward(void* stream, const adh_conv_desc* d);
+int adh_pack_weights_stem(void* stream, const float* src, const adh_wlayout* L, float* wp);
+
+/* Weight gradient of the 7x7 s1 p3 stem (3 -> 64 / 96 channels on the NHWC8 image; conv_stem.hip, MFMA 16x16x4 with the
+ * (kx, c) filter entries packed along the tile rows).  adh_conv_wgrad_stem_slabs(d) = number of slabs [49][8][NcP] the
+ * launch writes (0: not the stem); add them with adh_wgrad_reduce_small(slab, n, 8, NcP, L, dW).  Replaces the weight half
+ * of ATen's conv2d backward for init_conv (/root/reference models/dehazing/high_intensity.py:24). */
+int adh_conv_wgrad_stem_slabs(const adh_conv_desc* d);
+int adh_conv_wgrad_stem(void* stream, const adh_conv_desc* d, float* slab, int NcP);
+
 /* Weight gradient of the same layers in the F(4x4,3x3) Winograd domain (conv_wgrad43.hip): 1/4 of the direct MFMA
  * work.  Needs Cin % 96 == 0, Cout % 96 == 0, H % 4 == 0, W % 4 == 0 (adh_conv_wgrad_wino43_groups(d) > 0: its value is
  * the number of workgroups per pixel split of each of the three launches, one per frequency-row pair).  d->in = x,

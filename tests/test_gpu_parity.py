@@ -418,6 +418,62 @@ def test_small_channel_weight_gradient(N, Ci, Co, Hh, Ww, monkeypatch):
     assert float((got[True] - ref).abs().max()) < 2e-5 * scale
 
 
+@pytest.mark.parametrize("N,Co,Hh,Ww", [(2, 96, 13, 70), (1, 64, 8, 64), (1, 96, 21, 130), (2, 64, 5, 9)])
+def test_stem_forward_matches_general_kernel(N, Co, Hh, Ww, monkeypatch):
+    """conv_stem_fwd_kernel against the general gather kernel and the fp64 definition: output with bias, BatchNorm
+    partial statistics, and the fused scale / shift + ReLU epilogue."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(Co * 3 + Hh)
+    x = torch.zeros(N, Hh, Ww, 8)
+    x[..., :3] = torch.randn(N, Hh, Ww, 3, generator=g)
+    w = (torch.randn(Co, 3, 7, 7, generator=g) / 147 ** 0.5).to(DEV)
+    b = torch.randn(Co, generator=g).to(DEV)
+    sc = (torch.rand(Co, generator=g) + 0.5).to(DEV)
+    ref = F.conv2d(x[..., :3].permute(0, 3, 1, 2).double(), w.cpu().double(), b.cpu().double(), padding=3).permute(0, 2, 3, 1)
+    got = {}
+    for small in (False, True):
+        monkeypatch.setattr(E, "USE_SMALL_WGRAD", small)
+        eng = Engine(torch.device(DEV), record=False)
+        plans = eng._launch_plan("conv", 7, 1, 3, w, "fwd")
+        y = torch.zeros(N, Hh, Ww, Co, device=DEV)
+        stats, nblk = eng._run_gather(plans, Act(x.to(DEV), 8), y, Co, w, shift=b, want_stats=True)
+        y2 = torch.zeros(N, Hh, Ww, Co, device=DEV)
+        eng._run_gather(plans, Act(x.to(DEV), 8), y2, Co, w, scale=sc, shift=b, act=1)
+        torch.cuda.synchronize()
+        got[small] = (y.cpu().double(), stats.view(nblk, 2, -1).double().sum(0)[:, :Co].cpu(), y2.cpu().double())
+    scale = float(ref.abs().max())
+    for small in (False, True):
+        assert float((got[small][0] - ref).abs().max()) < 5e-6 * scale
+    ref2 = torch.relu((ref - b.cpu().double()) * sc.cpu().double() + b.cpu().double())
+    assert float((got[True][2] - got[False][2]).abs().max()) < 5e-6 * scale
+    assert float((got[True][2] - ref2).abs().max()) < 1e-5 * scale
+    ref_s = torch.stack([ref.sum((0, 1, 2)), (ref * ref).sum((0, 1, 2))])
+    assert float((got[True][1] - ref_s).abs().max()) < 2e-5 * float(ref_s.abs().max())
+
+
+@pytest.mark.parametrize("N,Co,Hh,Ww", [(2, 96, 13, 70), (1, 64, 8, 64), (1, 96, 21, 130), (2, 64, 5, 9)])
+def test_stem_weight_gradient(N, Co, Hh, Ww, monkeypatch):
+    """conv_wgrad_stem_kernel (7x7 stem on the NHWC8 image, (kx, c)-packed 16x16x4 tiles) against the packed general
+    kernel and the fp64 definition, with ragged tiles."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(Co + Hh)
+    x = torch.zeros(N, Hh, Ww, 8)
+    x[..., :3] = torch.randn(N, Hh, Ww, 3, generator=g)
+    gy = torch.randn(N, Hh, Ww, Co, generator=g)
+    w = torch.zeros(Co, 3, 7, 7, device=DEV, requires_grad=True)
+    ref = torch.nn.grad.conv2d_weight(x[..., :3].permute(0, 3, 1, 2).double(), (Co, 3, 7, 7), gy.permute(0, 3, 1, 2).double(),
+                                      stride=1, padding=3)
+    got = {}
+    for small in (False, True):
+        monkeypatch.setattr(E, "USE_SMALL_WGRAD", small)
+        eng = Engine(torch.device(DEV), record=False)
+        plans = eng._launch_plan("conv", 7, 1, 3, w, "fwd")
+        got[small] = eng._wgrad(plans, Act(x.to(DEV), 8), gy.to(DEV), Co, w).cpu().double()
+    scale = float(ref.abs().max())
+    assert float((got[False] - ref).abs().max()) < 2e-5 * scale
+    assert float((got[True] - ref).abs().max()) < 2e-5 * scale
+
+
 @pytest.mark.parametrize("kind,N,Ci,Co,Hh,Ww", [("conv", 1, 32, 96, 48, 96), ("conv", 2, 16, 64, 26, 50), ("conv", 1, 96, 192, 24, 192),
                                                 ("convT", 1, 64, 96, 12, 48), ("convT", 2, 32, 32, 13, 25), ("convT", 1, 16, 192, 24, 96)])
 def test_winograd32_matches_direct_path(kind, N, Ci, Co, Hh, Ww, monkeypatch):
