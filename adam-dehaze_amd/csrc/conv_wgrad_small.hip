@@ -119,6 +119,111 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const adh_conv_de
     }
 }
 
+// Few OUTPUT channels (the 48 -> 3 output convolution): the roles are exchanged -- the tile rows are (tap, co) pairs
+// packed with pitch COUT = 4 (36 rows = 3 tiles instead of 9 taps x 3 channel blocks = 27 tiles), the columns are 16
+// input channels:  D[(tap, co)][ci] += A[(tap, co)][4 px] B[4 px][ci],  A = g[pixel - tap + 1][co] from the LDS halo of
+// the output gradient (per-lane offset), B = x[pixel][ci] from the LDS tile of x (no halo).
+template <int XC, int GC, int COUT>
+__global__ __launch_bounds__(256) void conv_wgrad_fewout_kernel(const adh_conv_desc d, int tiles_x, int tiles_y, int ntiles,
+                                                                float* __restrict__ slab, int KP, int NcP) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CJB = XC / 16;                   // column tiles (input channels)
+    constexpr int RT = (9 * COUT + 15) / 16;       // row tiles
+    constexpr int GS_F = 6 * 66 * GC + 16;
+    float* const gs = lds;                         // g halo [6][66][GC]: rows y0-1 .. y0+4, columns x0-1 .. x0+64
+    float* const xs = lds + GS_F;                  // x tile [4][64][XC]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i16 = lane & 15, kk = lane >> 4;
+    int aoff[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int rI = adh_min_i(t * 16 + i16, 9 * COUT - 1);
+        const int tap = rI / COUT, co = rI - tap * COUT;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        aoff[t] = ((2 - dy) * 66 + (2 - dx)) * GC + co;
+    }
+    f32x4s acc[RT * CJB];
+#pragma unroll
+    for (int t = 0; t < RT * CJB; ++t) acc[t] = f32x4s{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int r = tile;
+        const int tx = r % tiles_x;
+        r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int n = r / tiles_y;
+        const int y0 = ty * 4, x0 = tx * 64;
+        const float* xin = d.in + (int64_t)n * d.IH * d.IW * XC;
+        const float* gin = d.out + (int64_t)n * d.VH * d.VW * GC;
+        __syncthreads();
+        constexpr int GQ = GC / 4;
+        for (int i = tid; i < 6 * 66 * GQ; i += 256) {
+            const int px = i / GQ, q = i - px * GQ;
+            const int row = px / 66, col = px - row * 66;
+            const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+            f32x4s v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < d.VH && gx >= 0 && gx < d.VW) v = *reinterpret_cast<const f32x4s*>(gin + ((int64_t)gy * d.VW + gx) * GC + q * 4);
+            *reinterpret_cast<f32x4s*>(gs + px * GC + q * 4) = v;
+        }
+        constexpr int XQ = XC / 4;
+        for (int i = tid; i < 4 * 64 * XQ; i += 256) {
+            const int px = i / XQ, q = i - px * XQ;
+            const int row = px >> 6, col = px & 63;
+            const int iy = y0 + row, ix = x0 + col;
+            f32x4s v = {0.f, 0.f, 0.f, 0.f};
+            if (iy < d.IH && ix < d.IW) v = *reinterpret_cast<const f32x4s*>(xin + ((int64_t)iy * d.IW + ix) * XC + q * 4);
+            *reinterpret_cast<f32x4s*>(xs + px * XC + q * 4) = v;
+        }
+        if (tid < 16) gs[6 * 66 * GC + tid] = 0.f;
+        __syncthreads();
+        const float* gl = gs + (wave * 66 + kk) * GC;
+        const float* xl = xs + (wave * 64 + kk) * XC + i16;
+#pragma unroll 4
+        for (int kg = 0; kg < 16; ++kg) {
+            float a[RT], b[CJB];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) a[t] = gl[kg * 4 * GC + aoff[t]];
+#pragma unroll
+            for (int c = 0; c < CJB; ++c) b[c] = xl[kg * 4 * XC + c * 16];
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int c = 0; c < CJB; ++c)
+                    acc[t * CJB + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[c], acc[t * CJB + c], 0, 0, 0);
+        }
+    }
+    float* red = lds;   // [RT * CJB tiles][64 lanes][4]
+#pragma unroll 1
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < RT * CJB; ++t) *reinterpret_cast<f32x4s*>(red + (t * 64 + lane) * 4) = acc[t];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < RT * CJB; ++t) acc[t] += *reinterpret_cast<const f32x4s*>(red + (t * 64 + lane) * 4);
+        }
+    }
+    if (wave == 0) {
+        float* const sl = slab + (int64_t)blockIdx.x * 9 * KP * NcP;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int c = 0; c < CJB; ++c)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int rI = t * 16 + 4 * kk + rr;          // D layout: row = 4 * (lane / 16) + reg, column = lane % 16
+                    const int tap = rI / COUT, co = rI - tap * COUT;
+                    const int ci = c * 16 + i16;
+                    if (rI < 9 * COUT && ci < KP) sl[((int64_t)tap * KP + ci) * NcP + co] = acc[t * CJB + c][rr];
+                }
+    }
+}
+
 static int small_combo(const adh_conv_desc* d) {
     if (!d) return 0;
     if (d->KH != 3 || d->KW != 3 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1) return 0;
@@ -126,7 +231,7 @@ static int small_combo(const adh_conv_desc* d) {
     if (d->VH != d->IH || d->VW != d->IW || d->Cin > d->in_cstride || d->Cout > 16 || d->Cout > d->out_cstride) return 0;
     if (d->in_cstride == 8 && d->out_cstride == 16 && d->Cin <= 8) return 1;
     if (d->in_cstride == 16 && d->out_cstride == 16) return 2;
-    if (d->in_cstride == 48 && d->out_cstride == 8) return 3;
+    if (d->in_cstride == 48 && d->out_cstride == 8) return d->Cout <= 4 ? 4 : 3;
     return 0;
 }
 
@@ -156,7 +261,14 @@ extern "C" int adh_conv_wgrad_small(void* stream, const adh_conv_desc* d, float*
     }
     if (combo == 1) SMALL_LAUNCH(8, 16, 1)
     else if (combo == 2) SMALL_LAUNCH(16, 16, 1)
-    else SMALL_LAUNCH(48, 8, 3)
+    else if (combo == 3) SMALL_LAUNCH(48, 8, 3)
+    else {
+        const int ldsb = (6 * 66 * 8 + 16 + 4 * 64 * 48) * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_fewout_kernel<48, 8, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+        hipLaunchKernelGGL((conv_wgrad_fewout_kernel<48, 8, 4>), dim3(nwg), dim3(256), ldsb, s, *d, tiles_x, tiles_y, ntiles, slab, KP,
+                           NcP);
+    }
 #undef SMALL_LAUNCH
     return adh_check_launch();
 }
