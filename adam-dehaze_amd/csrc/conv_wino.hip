@@ -28,6 +28,9 @@
 // Epilogue: accumulators -> LDS M[freq][tile][co] (one 32-channel tile at a time), all threads apply A^T M A
 // and the fused epilogue.
 #include "common.h"
+#ifndef W3_DBG
+#define W3_DBG 0   // dev builds of conv_wino32_kernel: 1 = skip the input transform, 2 = skip the contraction, 4 = skip the epilogue, 8 = no staging inside the loop
+#endif
 #include <cstdlib>
 
 #define W2_KC 16
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     fix_raw(nslabs > 1 ? 1 : 0, 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    transform(0);
+    if (!(W3_DBG & 1)) transform(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -692,10 +695,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
         // flight) to land, instead of two groups
         const int s2 = s + 2 < nslabs ? s + 2 : s;     // the last two slabs re-issue an earlier tile: uniform counts
         const int sn = s + 1 < nslabs ? s + 1 : s;
+        if (!(W3_DBG & 2)) {
         load_a(0, 0, av[0]);
         w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 1, 0));
         load_a(1, 0, av[1]);
-        w2_wait_b<NT + 10, NT>(bv[0]);       // (the previous slab's 10 raw pieces may still be in flight)
+        w2_wait_b<NT + ((W3_DBG & 8) ? 0 : 10), NT>(bv[0]);       // (the previous slab's 10 raw pieces may still be in flight)
         w2_group<NT, 0, 0, 0, 0>(acc, av[0], bv[0]);
 
         w2_load_b<NT>(bv[0], b_voff, b_ptr(s, 2, 0));
@@ -729,19 +733,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
         w2_group<NT, 2, 0, 0, 0>(acc, av[0], bv[0]);
 
         w2_load_b<NT>(bv[0], b_voff, b_ptr(sn, 0, 0));
-        stage_raw(s2, s & 1);
-        w2_wait_b<NT + 10, NT>(bv[1]);
+        if (!(W3_DBG & 8)) stage_raw(s2, s & 1);
+        w2_wait_b<NT + ((W3_DBG & 8) ? 0 : 10), NT>(bv[1]);
         w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
+        }
         // ---- V is free once every wave is here; raw(s+1) landed during this slab (second wait above)
         fix_raw(sn, (s + 1) & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        transform((s + 1) & 1);              // (after the last slab: a harmless re-transform, keeps the span branch-free)
+        if (!(W3_DBG & 1)) transform((s + 1) & 1);              // (after the last slab: a harmless re-transform, keeps the span branch-free)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
     w2_wait_b<0, NT>(bv[0]);
 
+    if (W3_DBG & 4) return;
     // ---------------------------------------------------------------------- output transform G^T M G + fused epilogue
     // One 32-channel tile at a time: accumulators -> M[16][64 tile rows][32 co] in LDS (tile t sits in row t' = t with its
     // low three bits rotated, so the two lane halves -- tiles t and t + 4 -- hit different banks), then thread = (tile,
