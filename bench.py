@@ -285,6 +285,7 @@ def main():
         step()
     # timed region: exactly K steps between barrier + synchronize on both sides
     timer = H.KernelTimer({"adh_conv_forward", "adh_conv_wino43_forward", "adh_conv_wino_forward", "adh_conv_wino32_forward", "adh_conv_wgrad",
+                           "adh_conv_stem_forward", "adh_conv_wgrad_stem", "adh_conv_wgrad_small", "adh_conv_wgrad_wino43",
                            "adh_conv_wgrad_wino"})
     H.TIMER = timer
     if world > 1:
@@ -313,7 +314,11 @@ def main():
                  "adh_conv_forward": "conv_rows_kernel / conv_igemm_kernel (direct fwd + dgrad launches: stems, heads, "
                                      "ragged shapes)",
                  "adh_conv_wgrad_wino": "conv_wgrad_rows_kernel<WINO> (Winograd-domain weight gradients of 3x3 s1)",
-                 "adh_conv_wgrad": "conv_wgrad_rows_kernel / conv_wgrad_kernel (direct weight gradients)"}
+                 "adh_conv_wgrad": "conv_wgrad_rows_kernel / conv_wgrad_kernel (direct weight gradients)",
+                 "adh_conv_wgrad_wino43": "conv_wgrad_wino43_kernel (F(4x4,3x3)-domain weight gradients; opt-in)",
+                 "adh_conv_stem_forward": "conv_stem_fwd_kernel (7x7 stem, 16x16x4 tiles)",
+                 "adh_conv_wgrad_stem": "conv_wgrad_stem_kernel (7x7 stem weight gradient, 16x16x4 tiles)",
+                 "adh_conv_wgrad_small": "conv_wgrad_small_kernel / conv_wgrad_fewout_kernel (few-channel 3x3 weight gradients)"}
         per = {}
         for key, label in names.items():
             k = ks.get(key, zero)
