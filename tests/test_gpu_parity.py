@@ -418,6 +418,73 @@ def test_small_channel_weight_gradient(N, Ci, Co, Hh, Ww, monkeypatch):
     assert float((got[True] - ref).abs().max()) < 2e-5 * scale
 
 
+@pytest.mark.parametrize("Ci,Co,k", [(96, 96, 3), (16, 16, 3), (3, 96, 7)])
+def test_full_size_weight_gradient_is_sum_over_images(Ci, Co, k):
+    """Weight gradients at the headline resolution (4 x 512 x 1024): the whole batch in one launch (hundreds of pixel
+    splits / slabs) against the sum of the per-image launches (a different split geometry), for the Winograd-domain
+    kernel, the few-channel kernel and the stem kernel."""
+    g = torch.Generator().manual_seed(Ci + Co)
+    N, Hh, Ww = 4, 512, 1024
+    Ca = (Ci + 7) // 8 * 8
+    x = torch.zeros(N, Hh, Ww, Ca, device=DEV)
+    x[..., :Ci] = torch.randn(N, Hh, Ww, Ci, device=DEV)
+    gy = torch.randn(N, Hh, Ww, Co, device=DEV)
+    w = torch.zeros(Co, Ci, k, k, device=DEV, requires_grad=True)
+    eng = Engine(torch.device(DEV), record=False)
+    plans = eng._launch_plan("conv", k, 1, k // 2, w, "fwd")
+    whole = eng._wgrad(plans, Act(x, Ca if Ci == 3 else Ci), gy, Co, w).double()
+    parts = torch.zeros_like(whole)
+    for n in range(N):
+        parts += eng._wgrad(plans, Act(x[n:n + 1].contiguous(), Ca if Ci == 3 else Ci), gy[n:n + 1].contiguous(), Co, w).double()
+    torch.cuda.synchronize()
+    assert float((whole - parts).abs().max()) < 2e-5 * float(parts.abs().max())
+
+
+def test_full_size_layers_linearity_and_crops(monkeypatch):
+    """The headline layer shape (8 x 512 x 1024 x 96, 1.6 GB per tensor) through conv_wino43_kernel and the stem kernels:
+    linearity conv(x1 + x2) = conv(x1) + conv(x2), and windows of the last image (largest offsets) against the fp64
+    definition computed on the crop -- size-independent checks where the CPU oracle cannot run the whole tensor."""
+    g = torch.Generator().manual_seed(11)
+    N, Hh, Ww, C = 8, 512, 1024, 96
+    eng = Engine(torch.device(DEV), record=False)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(DEV)
+    x1 = torch.randn(N, Hh, Ww, C, device=DEV)
+    x2 = torch.randn(N, Hh, Ww, C, device=DEV)
+    plans = eng._launch_plan("conv", 3, 1, 1, w, "fwd")
+    y1 = torch.empty(N, Hh, Ww, C, device=DEV)
+    y2 = torch.empty(N, Hh, Ww, C, device=DEV)
+    eng._run_gather(plans, Act(x1), y1, C, w)
+    eng._run_gather(plans, Act(x2), y2, C, w)
+    y1 += y2
+    x1 += x2
+    eng._run_gather(plans, Act(x1), y2, C, w)          # y2 = conv(x1 + x2)
+    torch.cuda.synchronize()
+    scale = float(y2.abs().max())
+    assert float((y1 - y2).abs().max()) < 2e-5 * scale
+    for (n, ya, xa) in ((7, 470, 960), (0, 0, 0), (3, 250, 500)):      # bottom-right corner, top-left corner, interior
+        ys, xs = max(ya - 1, 0), max(xa - 1, 0)
+        crop = x1[n, ys:ya + 41, xs:xa + 65].permute(2, 0, 1)[None].cpu().double()
+        ref = F.conv2d(F.pad(crop, (1, 1, 1, 1)), w.cpu().double())[0].permute(1, 2, 0)
+        oy, ox = ya - ys, xa - xs
+        hh, ww = min(40, Hh - ya), min(64, Ww - xa)
+        # rows / columns of the crop that are interior to the image window (not affected by the crop's own zero padding)
+        got = y2[n, ya:ya + hh, xa:xa + ww].cpu().double()
+        want = ref[oy:oy + hh, ox:ox + ww]
+        inner = (slice(0, hh - (0 if ya + 41 >= Hh else 1)), slice(0, ww - (0 if xa + 65 >= Ww else 1)))
+        assert float((got[inner] - want[inner]).abs().max()) < 1e-5 * scale
+    del x2, y1
+    # stem: 8 x 512 x 1024 image -> 96 channels
+    ws = (torch.randn(C, 3, 7, 7, generator=g) / 147 ** 0.5).to(DEV)
+    img = torch.zeros(N, Hh, Ww, 8, device=DEV)
+    img[..., :3] = torch.rand(N, Hh, Ww, 3, device=DEV)
+    eng._run_gather(eng._launch_plan("conv", 7, 1, 3, ws, "fwd"), Act(img, 8), y2, C, ws)
+    torch.cuda.synchronize()
+    n, ya, xa = 7, 440, 930
+    crop = img[n, ya - 3:ya + 43, xa - 3:xa + 67, :3].permute(2, 0, 1)[None].cpu().double()
+    ref = F.conv2d(crop, ws.cpu().double())[0].permute(1, 2, 0)
+    assert float((y2[n, ya:ya + 40, xa:xa + 64].cpu().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("N,Co,Hh,Ww", [(2, 96, 13, 70), (1, 64, 8, 64), (1, 96, 21, 130), (2, 64, 5, 9)])
 def test_stem_forward_matches_general_kernel(N, Co, Hh, Ww, monkeypatch):
     """conv_stem_fwd_kernel against the general gather kernel and the fp64 definition: output with bias, BatchNorm
