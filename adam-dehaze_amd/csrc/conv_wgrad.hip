@@ -451,42 +451,47 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
             const float* xb = smem + cur * BUF + (rB * WR_HP + 2 * h) * 32 + l31;
             const float* gp = smem + cur * BUF + XF + (rP * 32 + 2 * h) * 32 + l31;
             const float* gq = smem + cur * BUF + XF + (32 + 2 * h) * 32 + l31;
-            float ra[2][4], rb[2][4], gr[2][TN][4];
-            auto ld = [&](int tr, int sp, float (&va)[4], float (&vb)[4], float (&vg)[TN][4]) {
+            // Packed arithmetic: adjacent tile columns sit in register pairs (ds_read2_b32, second offset + one pixel), so
+            // every transform step is one v_pk_* on two columns:
+            //   (r0, r1), (r2, r3) = va + sg * vb                                  2 x v_pk_fma
+            //   (V0, V1) = (r0 - r2, r1 + r2),  (V3, -V2) = (r1 - r3, r1 - r2)      2 x v_pk_add (lane selects + sign modifiers)
+            //   (t0, t1) = gP + be * gQ,  (M1, -M2) = (t0 + t1, t1 - t0)           2 per n-tile
+            // (V2 and M2 both carry a minus sign: their product does not.)  10 VALU per 12 MFMAs instead of 20.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 ra[2][2], rb[2][2], gP[2][TN], gQ[2][TN];
+            auto ld = [&](int tr, int sp, f32x2 (&va)[2], f32x2 (&vb)[2], f32x2 (&vp)[TN], f32x2 (&vq)[TN]) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    va[c] = xa[((2 * tr) * WR_HP + 4 * sp + c) * 32];
-                    vb[c] = xb[((2 * tr) * WR_HP + 4 * sp + c) * 32];
+                for (int c = 0; c < 2; ++c) {
+                    va[c] = f32x2{xa[((2 * tr) * WR_HP + 4 * sp + 2 * c) * 32], xa[((2 * tr) * WR_HP + 4 * sp + 2 * c + 1) * 32]};
+                    vb[c] = f32x2{xb[((2 * tr) * WR_HP + 4 * sp + 2 * c) * 32], xb[((2 * tr) * WR_HP + 4 * sp + 2 * c + 1) * 32]};
                 }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)   // e = 2*i + jj: row pointer (gp, gq), output column jj of the tile
-                        vg[j][e] = ((e >> 1) ? gq : gp)[(j * 128 + (2 * tr) * 32 + 4 * sp + (e & 1)) * 32];
+                for (int j = 0; j < TN; ++j) {   // output columns 0, 1 of the tile: rows P and Q of the wave's frequency row
+                    vp[j] = f32x2{gp[(j * 128 + (2 * tr) * 32 + 4 * sp) * 32], gp[(j * 128 + (2 * tr) * 32 + 4 * sp + 1) * 32]};
+                    vq[j] = f32x2{gq[(j * 128 + (2 * tr) * 32 + 4 * sp) * 32], gq[(j * 128 + (2 * tr) * 32 + 4 * sp + 1) * 32]};
+                }
             };
-            ld(0, 0, ra[0], rb[0], gr[0]);
+            ld(0, 0, ra[0], rb[0], gP[0], gQ[0]);
 #pragma unroll
             for (int st = 0; st < 16; ++st) {
-                if (st + 1 < 16) ld((st + 1) >> 3, (st + 1) & 7, ra[(st + 1) & 1], rb[(st + 1) & 1], gr[(st + 1) & 1]);
-                const float(&va)[4] = ra[st & 1];
-                const float(&vb)[4] = rb[st & 1];
-                float r[4], V[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) r[c] = fmaf(sg, vb[c], va[c]);
-                V[0] = r[0] - r[2];
-                V[1] = r[1] + r[2];
-                V[2] = r[2] - r[1];
-                V[3] = r[1] - r[3];
+                if (st + 1 < 16)
+                    ld((st + 1) >> 3, (st + 1) & 7, ra[(st + 1) & 1], rb[(st + 1) & 1], gP[(st + 1) & 1], gQ[(st + 1) & 1]);
+                const f32x2 r01 = sg * rb[st & 1][0] + ra[st & 1][0];
+                const f32x2 r23 = sg * rb[st & 1][1] + ra[st & 1][1];
+                f32x2 v01, v32;   // (V0, V1), (V3, -V2)
+                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(v01) : "v"(r01), "v"(r23));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v32) : "v"(r01), "v"(r23));
+                float V[4] = {v01.x, v01.y, v32.y, v32.x};
                 float M[TN][4];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const float(&vg)[4] = gr[st & 1][j];
-                    const float t0 = fmaf(be, vg[2], vg[0]);
-                    const float t1 = fmaf(be, vg[3], vg[1]);
-                    M[j][0] = t0;
-                    M[j][1] = t0 + t1;
-                    M[j][2] = t0 - t1;
-                    M[j][3] = t1;
+                    const f32x2 t = be * gQ[st & 1][j] + gP[st & 1][j];
+                    f32x2 m12;    // (M1, -M2) = (t0 + t1, t1 - t0)
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(m12) : "v"(t), "v"(t));
+                    M[j][0] = t.x;
+                    M[j][1] = m12.x;
+                    M[j][2] = m12.y;
+                    M[j][3] = t.y;
                 }
                 wr_mfma_wino<TN, 0>(acc, V, M);
                 __builtin_amdgcn_sched_barrier(0);
