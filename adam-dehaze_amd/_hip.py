@@ -36,6 +36,11 @@ class ConvDesc(C.Structure):
     ]
 
 
+class AdamTensor(C.Structure):
+    """struct adh_adam_tensor."""
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("step", i32), ("repeats", i32)]
+
+
 class WLayout(C.Structure):
     """struct adh_wlayout."""
     _fields_ = [
@@ -134,6 +139,13 @@ _SIGNATURES = {
     "adh_lpips_layer_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "adh_rows_sum": [vp, vp, i32, i32, f32, vp, i32],
     "adh_adam_step": [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32],
+    "adh_adam_chunk_elems": [],
+    "adh_adam_multi": [vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, i32, i32],
+    "adh_apply_fog": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "adh_psnr_num_blocks": [i64],
+    "adh_psnr": [vp, vp, vp, i32, i64, f32, vp, i32, vp, vp],
+    "adh_ssim_num_blocks": [i32, i32],
+    "adh_ssim_gray": [vp, vp, vp, i32, i32, i32, f32, vp, i32, vp],
     "adh_add_inplace": [vp, vp, vp, i64],
     "adh_axpby_strided": [vp, vp, i32, vp, i32, i64, i32, f32, f32],
     "adh_maxpool": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
@@ -149,7 +161,8 @@ _SIGNATURES = {
 _VALUE_FUNCS = {"adh_version", "adh_conv_wino_supported", "adh_conv_wino_num_blocks", "adh_conv_wino32_supported", "adh_conv_wino43_supported", "adh_conv_wino43_num_blocks",
                 "adh_conv_wino32_num_blocks", "adh_conv_wgrad_wino_groups", "adh_conv_wgrad_wino43_groups", "adh_conv_wgrad_small_slabs", "adh_conv_wgrad_stem_slabs", "adh_conv_stem_num_blocks", "adh_conv_wgrad_slabs", "adh_conv_wgrad_groups", "adh_conv_lds_bytes", "adh_conv_num_blocks", "adh_bn_bwd_num_blocks",
                 "adh_cbam_pool_num_blocks", "adh_cbam_bwd_b_num_blocks", "adh_head_blend_bwd_num_blocks",
-                "adh_reduce_num_blocks", "adh_lpips_layer_num_blocks"}
+                "adh_reduce_num_blocks", "adh_lpips_layer_num_blocks", "adh_adam_chunk_elems", "adh_psnr_num_blocks",
+                "adh_ssim_num_blocks"}
 
 _ERRORS = {-1: "ADH_E_ARG (bad argument: shape / alignment / null pointer)",
            -2: "ADH_E_LAUNCH (hip kernel launch failed)",

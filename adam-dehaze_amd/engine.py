@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -33,6 +34,37 @@ _WINO_ONLY = os.environ.get("ADH_WINOGRAD_ONLY", "")   # dev: "fwd" or "dgrad" r
 
 def _round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Packed / Winograd-transformed weights are a function of the parameter only: cache them per parameter *version* so that
+# the forward pass and the data gradient of one step (and every pass of an eval loop) share one pack launch.
+# Key: (id, data_ptr, torch version counter, kind, layout).  torch bumps the version counter on every in-place op
+# (optimizers, load_state_dict's copy_); writers that bypass it -- the HIP Adam kernel, or `p.data.op_()` -- must call
+# `invalidate_weight_cache()` (optim.Adam.step does).  ADH_PACK_CACHE=0 disables the cache.
+# ---------------------------------------------------------------------------------------------------------------------
+USE_PACK_CACHE = os.environ.get("ADH_PACK_CACHE", "1") != "0"
+_PACK_CACHE: Dict[tuple, Tuple["weakref.ref", torch.Tensor]] = {}
+_PACK_CACHE_MAX = 4096
+
+
+def invalidate_weight_cache() -> None:
+    _PACK_CACHE.clear()
+
+
+def _layout_key(L: WLayout) -> tuple:
+    return (L.K, L.Nc, L.KHt, L.KWt, L.tap_off0, L.tap_off_sy, L.tap_off_sx, L.stride_k, L.stride_n)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Gradient sinks and the grad-ready hook (data-parallel training, parallel.GradientSynchronizer).
+# GRAD_SINK(param) -> a preallocated contiguous tensor of the parameter's shape (a view of a flat bucket buffer) that the
+# engine writes the parameter's gradient into, or None; GRAD_READY(param, grad) is called from inside Engine.backward()
+# the moment the gradient is final (all of the parameter's uses in this engine have been processed), so a bucket's
+# all-reduce can start while the rest of the backward pass is still running.
+# ---------------------------------------------------------------------------------------------------------------------
+GRAD_SINK: Optional[Callable[[torch.Tensor], Optional[torch.Tensor]]] = None
+GRAD_READY: Optional[Callable[[torch.Tensor, torch.Tensor], None]] = None
 
 
 class Act:
@@ -107,6 +139,7 @@ class Engine:
         self.param_grads: Dict[int, torch.Tensor] = {}   # id(param) -> grad
         self.params: Dict[int, torch.Tensor] = {}
         self.alias: Dict[int, int] = {}                  # id(reshaped view of a param) -> id(param)
+        self.uses: Dict[int, int] = {}                   # id(param) -> uses recorded on the tape and not yet differentiated
         self.upstream: Dict[str, torch.Tensor] = {}      # 'g': device scalar cotangent of a scalar loss
         # None: follow USE_WINO43.  The loss networks set "dgrad": they difference the features of two nearly equal
         # images behind max-pools, so their forward pass keeps F(2x2,3x3) (whose rounding is below the direct kernel's)
@@ -116,6 +149,28 @@ class Engine:
     def _f(self, *shape, zero=False):
         return (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=torch.float32)
 
+    def use_param(self, *ps: Optional[torch.Tensor]):
+        """Forward-side bookkeeping: each recorded op declares the parameters its backward closure will add a gradient
+        for, so that `add_param_grad` knows when a gradient is final (GRAD_READY)."""
+        for p in ps:
+            if p is not None:
+                k = self.alias.get(id(p), id(p))
+                self.uses[k] = self.uses.get(k, 0) + 1
+
+    def grad_buffer(self, p: torch.Tensor, zero: bool = False) -> torch.Tensor:
+        """Where a backward closure should write the gradient of `p`: the registered sink (a view of a flat bucket
+        buffer) when there is one, it has not been used by an earlier op of this engine, and `p.grad` is not already
+        populated (gradient accumulation across backward passes must not alias); else a fresh tensor."""
+        k = self.alias.get(id(p), id(p))
+        if GRAD_SINK is not None and k == id(p) and k not in self.param_grads and getattr(p, "grad", None) is None:
+            buf = GRAD_SINK(p)
+            if buf is not None and buf.numel() == p.numel():
+                buf = buf.view(p.shape)
+                if zero:
+                    buf.zero_()
+                return buf
+        return self._f(*p.shape, zero=zero)
+
     def add_param_grad(self, p: torch.Tensor, g: torch.Tensor):
         k = self.alias.get(id(p), id(p))
         if k in self.param_grads:
@@ -123,6 +178,10 @@ class Engine:
         else:
             self.param_grads[k] = g
             self.params[k] = p
+        left = self.uses.get(k, 1) - 1
+        self.uses[k] = left
+        if left == 0 and GRAD_READY is not None:
+            GRAD_READY(self.params[k], self.param_grads[k])
 
     def accum(self, act: Act, g: torch.Tensor):
         """act.grad (+)= g ; g is [N,H,W,>=C] possibly strided."""
@@ -208,12 +267,29 @@ class Engine:
         d.NcP = NcP
         return d
 
+    def _packed(self, fn: str, w: torch.Tensor, L: WLayout, nfloats: int) -> torch.Tensor:
+        """Run the pack kernel `fn` (adh_pack_weights*) for (w, L), or return the cached result for this version of w."""
+        key = None
+        if USE_PACK_CACHE:
+            key = (id(w), w.data_ptr(), w._version, fn, _layout_key(L), nfloats, str(w.device))
+            hit = _PACK_CACHE.get(key)
+            if hit is not None and hit[0]() is w:
+                return hit[1]
+        wp = self._f(nfloats)
+        H.call(fn, w.data_ptr(), C.byref(L), wp.data_ptr())
+        if key is not None:
+            if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
+                _PACK_CACHE.clear()
+            try:
+                _PACK_CACHE[key] = (weakref.ref(w), wp)
+            except TypeError:
+                pass
+        return wp
+
     def _pack(self, w: torch.Tensor, L: WLayout) -> torch.Tensor:
         KQ = _round_up(L.K, 8) // 4
         NcP = _round_up(L.Nc, 32)
-        wp = self._f(L.KHt * L.KWt * KQ * NcP * 4)
-        H.call("adh_pack_weights", w.data_ptr(), C.byref(L), wp.data_ptr())
-        return wp
+        return self._packed("adh_pack_weights", w, L, L.KHt * L.KWt * KQ * NcP * 4)
 
     @staticmethod
     def _launch_plan(kind: str, k: int, stride: int, pad: int, w: torch.Tensor, direction: str):
@@ -292,16 +368,14 @@ class Engine:
                 if (w43 is True or w43 == ("dgrad" if gm["dstep"] == -1 else "fwd")) and \
                         H.value("adh_conv_wino43_supported", C.byref(d)):
                     wino = 43
-                    wp = self._f(36 * (Kp // 4) * NcP * 4)
-                    H.call("adh_pack_weights_wino43", w.data_ptr(), C.byref(Lw), wp.data_ptr())
+                    wp = self._packed("adh_pack_weights_wino43", w, Lw, 36 * (Kp // 4) * NcP * 4)
                 else:
                     wino = bool(H.value("adh_conv_wino_supported", C.byref(d)))
                 if wino == 43:
                     pass
                 elif wino:
                     KQ = Kp // 4
-                    wp = self._f(16 * KQ * NcP * 4)
-                    H.call("adh_pack_weights_wino", w.data_ptr(), C.byref(Lw), wp.data_ptr())
+                    wp = self._packed("adh_pack_weights_wino", w, Lw, 16 * KQ * NcP * 4)
                 else:
                     d.dy0 = d.dx0 = gm["dy0"]
                     d.dstep_y = d.dstep_x = gm["dstep"]
@@ -319,16 +393,14 @@ class Engine:
                 if H.value("adh_conv_wino32_supported", C.byref(d)):
                     wino = 32
                     ncls = 4 if gm["KH"] == 4 else 1
-                    wp = self._f(ncls * 16 * (Kp // 4) * NcP * 4)
-                    H.call("adh_pack_weights_wino32", w.data_ptr(), C.byref(Lw), wp.data_ptr())
+                    wp = self._packed("adh_pack_weights_wino32", w, Lw, ncls * 16 * (Kp // 4) * NcP * 4)
                 else:
                     d.dy0 = d.dx0 = gm["dy0"]
                     d.dstep_y = d.dstep_x = gm["dstep"]
             if not wino and gm["KH"] == 7 and L.K <= 3 and residual is None and USE_SMALL_WGRAD and \
                     H.value("adh_conv_stem_num_blocks", C.byref(d)):
                 wino = "stem"   # 7x7 stem on the NHWC8 image: (kx, c)-packed 16x16x4 tiles (conv_stem.hip)
-                wp = self._f(7 * 24 * NcP)
-                H.call("adh_pack_weights_stem", w.data_ptr(), C.byref(L), wp.data_ptr())
+                wp = self._packed("adh_pack_weights_stem", w, L, 7 * 24 * NcP)
             if not wino:
                 wp = self._pack(w, L)   # keep alive until the launch below is enqueued
             d.wp = wp.data_ptr()
@@ -370,7 +442,7 @@ class Engine:
 
     def _wgrad(self, plans, x: Act, g_y: torch.Tensor, gC: int, w: torch.Tensor) -> torch.Tensor:
         """Weight gradient in the parameter's own layout (OIHW / IOHW)."""
-        dw = self._f(*w.shape)
+        dw = self.grad_buffer(w)
         if x.C == 8 and x.cs == 8 and w.dim() == 4 and w.shape[1] <= 8 and w.shape[2] == 7 and len(plans) == 1 \
                 and plans[0][1]["in_s"] == 1:
             gm = plans[0][1]
@@ -535,6 +607,10 @@ class Engine:
 
         o = Act(out, Cout)
         if self.record:
+            # the parameters _conv_backward will produce a gradient for (must mirror its add_param_grad calls)
+            self.use_param(w if (w.requires_grad or self.alias.get(id(w)) is not None) else None, b,
+                           bn.weight if (bn is not None and training) else None,
+                           bn.bias if (bn is not None and training) else None)
             self.tape.append(lambda: self._conv_backward(x, w, b, bn, kind, k, stride, pad, relu, residual, o, saved))
         return o
 
@@ -563,7 +639,11 @@ class Engine:
             partial = self._f(nblk, 2, C4)
             H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
                    y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4, mask_ss)
-            dgamma, dbeta, coef = self._f(C4), self._f(C4), self._f(3, C4)
+            if C4 == Cout:
+                dgamma, dbeta = self.grad_buffer(bn.weight), self.grad_buffer(bn.bias)
+            else:
+                dgamma, dbeta = self._f(C4), self._f(C4)
+            coef = self._f(3, C4)
             H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), bn.weight.data_ptr(),
                    invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
             H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
@@ -634,6 +714,8 @@ class Engine:
                sa.data_ptr(), out.data_ptr(), out.stride(2))
         o = Act(out, Cc)
         if self.record:
+            self.use_param(wsp, w1, w2)
+
             def bwd():
                 g = o.grad
                 o.grad = None
@@ -645,14 +727,14 @@ class Engine:
                 nb = H.value("adh_cbam_bwd_b_num_blocks", N, Hh, Ww)
                 gsmap = self._f(N, HW, 2)
                 dwsp_partial = self._f(nb, 98)
-                dwsp = self._f(*wsp.shape)
+                dwsp = self.grad_buffer(wsp)
                 H.call("adh_cbam_bwd_b", gsa_pre.data_ptr(), smap.data_ptr(), wsp.data_ptr(), N, Hh, Ww,
                        gsmap.data_ptr(), dwsp_partial.data_ptr(), nb, dwsp.data_ptr(), 0)
                 gca_partial = self._f(N, nblk, Cc)
                 H.call("adh_cbam_bwd_c", g.data_ptr(), g.stride(2), x.t.data_ptr(), x.cs, sa.data_ptr(),
                        gsmap.data_ptr(), cidx.data_ptr(), N, HW, Cc, gca_partial.data_ptr(), nblk)
                 gpool = self._f(N, 2, Cc)
-                dw1, dw2 = self._f(*w1.shape), self._f(*w2.shape)
+                dw1, dw2 = self.grad_buffer(w1), self.grad_buffer(w2)
                 H.call("adh_cbam_bwd_d", gca_partial.data_ptr(), nblk, ca.data_ptr(), pooled.data_ptr(),
                        hidden.data_ptr(), w1.data_ptr(), w2.data_ptr(), N, Cc, Ch, gpool.data_ptr(), dw1.data_ptr(),
                        dw2.data_ptr(), 0)
@@ -814,6 +896,9 @@ class Engine:
                gd.cs if gd else 0, H.ptr(alpha), N, Hh, Ww, out.data_ptr())
         holder = {"g": None}
         if self.record:
+            if mode == 0:
+                self.use_param(alpha)
+
             def bwd():
                 g = holder["g"]
                 if g is None:
@@ -829,7 +914,7 @@ class Engine:
                 if gd:
                     self.accum(gd, g_gd)
                 if mode == 0:
-                    ga = self._f(1)
+                    ga = self.grad_buffer(alpha).reshape(1)
                     H.call("adh_sum_partials", ga_partial.data_ptr(), nb, 1.0, ga.data_ptr())
                     self.add_param_grad(alpha, ga.reshape(alpha.shape))
             self.tape.append(bwd)

@@ -2,62 +2,242 @@
 backend on ROCm) over xGMI.
 
 The reference is single-device (config.yaml:85); sharding the batch by image is the build's
-addition.  Every rank holds a full replica; after backward the gradients are summed
-across ranks and divided by the world size in a few large flat buckets (the whole model is ~65 MB,
-so 2-4 buckets keep each ring message well above the latency regime of the 7 x ~153 GB/s xGMI
-links) on a dedicated stream so the reduction of bucket i overlaps the flattening of bucket i+1.
-BatchNorm statistics stay per replica ("replica-BN", exactly PyTorch-DDP semantics).
-Works with the gloo backend on CPU tensors as well (world_size-2 CPU tests).
+addition.  Every rank holds a full replica; BatchNorm statistics stay per replica
+("replica-BN", exactly PyTorch-DDP semantics).  The only collective on the data path is the gradient
+all-reduce, organised for MI355X's point-to-point xGMI (7 links x ~153 GB/s per GPU, ring collectives are
+per-link bound): the whole model is 65-140 MB, so it travels as a handful of large flat buckets.
+
+* **Flat buckets, no copies.**  All gradients live in one pre-allocated flat fp32 buffer (`arena`); every
+  parameter owns a 256-byte-aligned slice of it.  `engine.GRAD_SINK` hands those slices to the backward
+  kernels, which write the weight gradients straight into them; a bucket is a contiguous range of the
+  arena and is all-reduced in place (`ReduceOp.AVG` on RCCL: no separate 1/world pass).  After `finish()`
+  `p.grad` *is* the slice.  Gradients produced elsewhere (torch autograd, small bias sums) are copied in.
+* **Overlap with backward.**  `engine.GRAD_READY` fires inside `Engine.backward()` the moment a
+  parameter's gradient is final; when the last parameter of bucket *i* has reported (and buckets < *i*
+  have been launched -- collectives must be issued in the same order on every rank) its all-reduce is
+  launched asynchronously: RCCL's stream waits for the kernels enqueued so far and runs beside the rest
+  of the backward pass.  The bucket layout follows the order in which gradients became ready during the
+  first step (rank 0's order, broadcast), like DDP's bucket rebuild.
+* **Unused parameters** (HardRouter: a rank may not run a branch).  `detect_unused=True` all-reduces a
+  has-gradient bitmap (MAX) so that parameters no rank produced keep `grad = None` -- Adam then skips
+  them exactly as the single-process reference does -- at the cost of one small D2H read per step;
+  with `detect_unused=False` every parameter ends with a (possibly zero) gradient.
+
+Works with the gloo backend as well (CPU tensors in the world-size-2 tests here; GPU tensors for a
+two-process rehearsal on one MI355X): gloo has no AVG, so SUM is followed by one in-place scale.
 """
 from __future__ import annotations
 
-from typing import List
+from typing import Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 
+_ALIGN = 64   # floats: 256-byte alignment of every slice (the reduce kernels store 16-byte vectors)
+
+
+def _is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
 
 class GradientSynchronizer:
-    def __init__(self, params: List[torch.Tensor], world_size: int, bucket_bytes: int = 32 << 20):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params: Iterable[torch.Tensor], world_size: int, bucket_bytes: int = 32 << 20,
+                 detect_unused: bool = False, rebuild: bool = True):
+        seen, self.params = set(), []
+        for p in params:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
         self.world = world_size
-        self.buckets: List[List[torch.Tensor]] = []
-        cur, cur_bytes = [], 0
-        for p in reversed(self.params):   # backward produces the last layers' gradients first
-            cur.append(p)
-            cur_bytes += p.numel() * 4
-            if cur_bytes >= bucket_bytes:
-                self.buckets.append(cur)
-                cur, cur_bytes = [], 0
-        if cur:
-            self.buckets.append(cur)
-        self._stream = None
+        self.bucket_bytes = bucket_bytes
+        self.detect_unused = detect_unused
+        self._rebuild_pending = rebuild and world_size > 1
+        self.index: Dict[int, int] = {id(p): i for i, p in enumerate(self.params)}
+        self.arena: Optional[torch.Tensor] = None
+        self._layout(list(reversed(range(len(self.params)))))   # backward produces the last layers' gradients first
+        self._installed = False
+        self._reset_step()
 
-    def all_reduce(self):
+    # ------------------------------------------------------------------ layout
+    def _layout(self, order: List[int]):
+        """Assign arena slices in `order` and cut buckets of >= bucket_bytes."""
+        self.order = order
+        self.offset = [0] * len(self.params)
+        self.buckets: List[dict] = []     # {start, end (floats), members [param index]}
+        off, start, members = 0, 0, []
+        for i in order:
+            self.offset[i] = off
+            off += (self.params[i].numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            members.append(i)
+            if (off - start) * 4 >= self.bucket_bytes:
+                self.buckets.append({"start": start, "end": off, "members": members})
+                start, members = off, []
+        if members:
+            self.buckets.append({"start": start, "end": off, "members": members})
+        self.total = off
+        self.bucket_of = [0] * len(self.params)
+        for b, bk in enumerate(self.buckets):
+            for i in bk["members"]:
+                self.bucket_of[i] = b
+        self.arena = None
+        self.views: List[Optional[torch.Tensor]] = [None] * len(self.params)
+
+    def _ensure_arena(self):
+        if self.arena is None and self.params:
+            dev = self.params[0].device
+            self.arena = torch.zeros(self.total, device=dev, dtype=torch.float32)
+            for i, p in enumerate(self.params):
+                self.views[i] = self.arena[self.offset[i]:self.offset[i] + p.numel()].view(p.shape)
+
+    def _reset_step(self):
+        self._ready = [False] * len(self.params)
+        self._pending = [len(bk["members"]) for bk in self.buckets]
+        self._next_bucket = 0
+        self._works: List = []
+        self._observed: List[int] = []
+        self._begun = False
+
+    # ------------------------------------------------------------------ engine hooks
+    def install(self):
+        """Route the engine's gradient buffers and grad-ready notifications through this synchronizer."""
+        from . import engine as E
+        E.GRAD_SINK, E.GRAD_READY = self._sink, self._on_ready
+        self._installed = True
+
+    def uninstall(self):
+        from . import engine as E
+        if self._installed and E.GRAD_READY == self._on_ready:
+            E.GRAD_SINK = E.GRAD_READY = None
+        self._installed = False
+
+    def _sink(self, p: torch.Tensor) -> Optional[torch.Tensor]:
+        i = self.index.get(id(p))
+        if i is None or not self._begun:
+            return None
+        return self.views[i]
+
+    def _on_ready(self, p: torch.Tensor, g: torch.Tensor):
+        i = self.index.get(id(p))
+        if i is None or not self._begun or self._ready[i]:
+            return
+        v = self.views[i]
+        if g.data_ptr() != v.data_ptr():
+            v.copy_(g.reshape(v.shape))
+        self._mark(i)
+
+    def _mark(self, i: int):
+        self._ready[i] = True
+        self._observed.append(i)
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        while self._next_bucket < len(self.buckets) and self._pending[self._next_bucket] == 0:
+            self._launch(self._next_bucket)
+            self._next_bucket += 1
+
+    def _launch(self, b: int):
         if self.world <= 1:
             return
-        on_gpu = self.params[0].is_cuda
-        if on_gpu and self._stream is None:
-            self._stream = torch.cuda.Stream()
-        flats, works = [], []
-        for bucket in self.buckets:
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            flats.append((flat, bucket))
-            if on_gpu:
-                self._stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._stream):
-                    works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-            else:
-                works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
+        bk = self.buckets[b]
+        flat = self.arena[bk["start"]:bk["end"]]
+        avg = dist.get_backend() == "nccl"
+        self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True))
+
+    # ------------------------------------------------------------------ step protocol
+    def begin_step(self):
+        """Call after zero_grad and before backward: clears the arena (slices nobody writes must read as zero) and arms
+        the engine hooks for this step."""
+        self._ensure_arena()
+        self._reset_step()
+        if self.arena is not None:
+            self.arena.zero_()
+        self._begun = True
+
+    def finish(self):
+        """Call after backward: take in the gradients that did not come through the engine hooks (p.grad set by torch
+        autograd), launch the remaining buckets in order, wait, and leave p.grad = the averaged slice."""
+        if not self._begun:
+            self.begin_step()
+        for i, p in enumerate(self.params):
+            if not self._ready[i] and p.grad is not None:
+                v = self.views[i]
+                if p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad.reshape(v.shape))
+                self._mark(i)
+        produced = list(self._ready)
+        # whatever is still pending (parameters without a gradient on this rank) goes out now, in bucket order
+        while self._next_bucket < len(self.buckets):
+            self._launch(self._next_bucket)
+            self._next_bucket += 1
+        if self.world > 1 and self.detect_unused:
+            mask = torch.tensor([1 if r else 0 for r in produced], dtype=torch.int32, device=self.arena.device)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+            produced = [bool(x) for x in mask.tolist()]
+        for w in self._works:
             w.wait()
-        if on_gpu:
-            torch.cuda.current_stream().wait_stream(self._stream)
-        inv = 1.0 / self.world
-        for flat, bucket in flats:
-            off = 0
-            for p in bucket:
-                n = p.numel()
-                p.grad = (flat[off:off + n] * inv).view_as(p)
-                off += n
+        if self.world > 1 and dist.get_backend() != "nccl":
+            self.arena.mul_(1.0 / self.world)
+        for i, p in enumerate(self.params):
+            if produced[i] or not self.detect_unused:
+                p.grad = self.views[i]
+            else:
+                p.grad = None
+        self._begun = False
+        if self._rebuild_pending:
+            self._rebuild_pending = False
+            self._rebuild_from_observed()
+
+    def all_reduce(self):
+        """Non-overlapped form: average whatever is in p.grad now (the round-1 API; finish() without the hooks)."""
+        if self.world <= 1:
+            return
+        if not self._begun:
+            self.begin_step()
+        self.finish()
+
+    def _rebuild_from_observed(self):
+        """Re-cut the buckets in the order gradients became ready in the first step (rank 0's order for everyone)."""
+        order = list(self._observed) + [i for i in self.order if not self._ready[i]]
+        if self.world > 1:
+            t = torch.tensor(order, dtype=torch.int64, device=self.arena.device if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(t, src=0)
+            order = [int(x) for x in t.tolist()]
+        if order != self.order:
+            # p.grad still points into the old arena, which stays alive through those views until zero_grad
+            self._layout(order)
+
+    # ------------------------------------------------------------------ replica consistency helpers
+    def broadcast_parameters(self, *modules: torch.nn.Module, src: int = 0):
+        """Make every rank start from rank `src`'s parameters and buffers (checkpoint loading, RNG-dependent init)."""
+        if self.world <= 1:
+            return
+        with torch.no_grad():
+            seen = set()
+            for m in modules:
+                for t in list(m.parameters()) + list(m.buffers()):
+                    if id(t) in seen:
+                        continue
+                    seen.add(id(t))
+                    dist.broadcast(t.data, src=src)
+        from .engine import invalidate_weight_cache
+        invalidate_weight_cache()
+
+
+def all_reduce_mean_scalar(value: float, device=None) -> float:
+    """Mean of a host scalar over the ranks (epoch metrics that drive ReduceLROnPlateau must agree on every rank, or the
+    replicas' learning rates diverge)."""
+    if not _is_dist() or dist.get_world_size() == 1:
+        return value
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([value], dtype=torch.float64, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item()) / dist.get_world_size()
+
+
+def all_ranks_any(flag: bool, device=None) -> bool:
+    """True if `flag` holds on any rank (a rank must not skip a step with a collective in it on its own)."""
+    if not _is_dist() or dist.get_world_size() == 1:
+        return flag
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item())

@@ -1,26 +1,44 @@
-"""The training steps of the hot path (/root/reference training/train_joint.py:29-166,
-training/train_dehazing.py:16-106) on the HIP engine, plus the data-parallel wrapper.
+"""The training / validation drivers of the hot path (/root/reference training/train_joint.py:29-310,
+training/train_dehazing.py:16-214) on the HIP engine, plus the data-parallel wrapper.
 
 `build_joint_system(config)` reproduces the reference's construction order (classifier, low, medium,
 high -> router -> optimiser -> scheduler -> criterion, train_joint.py:36-98) including the duplicated
 branch parameters in the optimiser's parameter list.  `joint_train_step` is the body of the hot loop
-(train_joint.py:129-166); `dehazing_train_step` the one of train_dehazing.py:71-106.
-Dataset I/O (cv2 image folders) is out of scope: `synthetic_loader` produces foggy frames with the
-reference's own fog model when no loader is supplied.
+(train_joint.py:129-166), `dehazing_train_step` the one of train_dehazing.py:71-106; `validate_joint` /
+`validate_dehazing` mirror the validation loops (train_joint.py:173-236, train_dehazing.py:109-166) with
+PSNR / SSIM computed on the device for whole batches (metrics.py) and ONE host read-back per epoch;
+checkpoints carry exactly the reference's keys (train_joint.py:272-283,291-302; train_dehazing.py:196-203,
+208-215) plus `scheduler_state_dict`, and `resume=` restores model, optimiser, scheduler, epoch and
+best-PSNR (the reference parses `--resume` and ignores it, main.py:50-51).
+Dataset I/O (cv2 image folders) is out of scope: `data.synthetic_loader` produces foggy frames on the GPU
+with the reference's own fog model when no loader is supplied.
+
+Data-parallel runs (torchrun, one process per GPU): replicas are made identical by broadcasting rank 0's
+parameters and buffers after construction / checkpoint loading; gradients go through
+`parallel.GradientSynchronizer` (flat buckets all-reduced while backward is still running); every
+host-side decision that steers training -- the metric given to ReduceLROnPlateau, "skip this step, the
+sub-batch is empty" -- is agreed across ranks first, so learning rates and step counts cannot diverge.
 """
 from __future__ import annotations
 
+import glob
 import os
-from typing import Dict, Iterator, Optional
+import re
+import warnings
+from typing import Dict, Iterable, Iterator, Optional
 
 import torch
 
 from .classifier import create_classifier
+from .data import synthetic_loader  # noqa: F401  (re-exported: round-1 callers import it from here)
 from .dehazing import create_high_intensity_model, create_low_intensity_model, create_medium_intensity_model
 from .loss import get_dehazing_loss, get_joint_loss
+from .metrics import psnr_batch, ssim_batch
 from .optim import Adam
-from .parallel import GradientSynchronizer
+from .parallel import GradientSynchronizer, all_ranks_any, all_reduce_mean_scalar
 from .routing import create_router
+
+LEVELS = {"low": 0, "medium": 1, "high": 2}
 
 
 class ReduceLROnPlateau:
@@ -41,6 +59,17 @@ class ReduceLROnPlateau:
                 gr["lr"] *= self.factor
             self.bad = 0
 
+    def state_dict(self):
+        return {"best": self.best, "num_bad_epochs": self.bad, "factor": self.factor, "patience": self.patience,
+                "threshold": self.threshold}
+
+    def load_state_dict(self, sd):
+        self.best, self.bad = sd["best"], sd["num_bad_epochs"]
+
+
+def _world_rank():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+
 
 def load_pretrained_model(model, checkpoint_path):
     """train_joint.py:18-27: missing checkpoints are not errors."""
@@ -53,7 +82,7 @@ def load_pretrained_model(model, checkpoint_path):
     return False
 
 
-def build_joint_system(config, world_size: int = 1) -> Dict:
+def build_joint_system(config, world_size: int = 1, adam_duplicates: str = "sequential") -> Dict:
     device = torch.device(config["device"])
     classifier = create_classifier(config)
     low = create_low_intensity_model(config)
@@ -68,10 +97,16 @@ def build_joint_system(config, world_size: int = 1) -> Dict:
     params = list(router.parameters())
     for m in models.values():
         params.extend(list(m.parameters()))
-    optimizer = Adam(params, lr=config["joint_training"]["learning_rate"], weight_decay=0.0001)
+    optimizer = Adam(params, lr=config["joint_training"]["learning_rate"], weight_decay=0.0001, duplicates=adam_duplicates)
     scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=0.5, patience=3)
     criterion = get_joint_loss(config).to(device)
-    sync = GradientSynchronizer(list(router.parameters()), world_size) if world_size > 1 else None
+    sync = None
+    if world_size > 1:
+        # a hard router leaves the branches a rank did not route to without gradients: agree on who produced what
+        hard = config.get("routing", {}).get("type", "soft") == "hard"
+        sync = GradientSynchronizer(list(router.parameters()), world_size, detect_unused=hard)
+        sync.broadcast_parameters(router)
+        sync.install()
     return {"classifier": classifier, "models": models, "router": router, "optimizer": optimizer,
             "scheduler": scheduler, "criterion": criterion, "sync": sync, "device": device}
 
@@ -80,109 +115,390 @@ def joint_train_step(system: Dict, batch: Dict) -> Dict:
     """One iteration of train_joint.py:129-166.  Losses stay on the device (no .item() sync)."""
     dev = system["device"]
     hazy, clear, labels = batch["hazy"].to(dev), batch["clear"].to(dev), batch["intensity"].to(dev)
+    sync = system["sync"]
     system["optimizer"].zero_grad()
+    if sync is not None:
+        sync.begin_step()
     logits, _ = system["classifier"](hazy)
     dehazed, _ = system["router"](hazy, logits)
     loss, comps = system["criterion"](dehazed, clear, logits, labels)
     loss.backward()
-    if system["sync"] is not None:
-        system["sync"].all_reduce()
+    if sync is not None:
+        sync.finish()
     system["optimizer"].step()
     return {"loss": loss.detach(), "dehazing": comps["dehazing"].detach(),
             "classification": comps["classification"].detach()}
 
 
 def dehazing_train_step(model, criterion, optimizer, batch: Dict, level: Optional[int], device, sync=None):
-    """One iteration of train_dehazing.py:71-106: keep only the images of this branch's fog level."""
+    """One iteration of train_dehazing.py:71-106: keep only the images of this branch's fog level.  Under data
+    parallelism a rank whose sub-batch is empty still takes part in the gradient all-reduce (with zeros) unless the
+    sub-batch is empty on EVERY rank, so no rank is left waiting in a collective."""
     hazy, clear, labels = batch["hazy"], batch["clear"], batch["intensity"]
     if level is not None:
         keep = labels == level
-        if int(keep.sum()) == 0:
+        empty = int(keep.sum()) == 0
+        if sync is not None and sync.world > 1:
+            if not all_ranks_any(not empty, device):
+                return None
+        elif empty:
             return None
         hazy, clear = hazy[keep], clear[keep]
-    hazy, clear = hazy.to(device), clear.to(device)
+    else:
+        empty = False
     optimizer.zero_grad()
-    out = model(hazy)
-    loss, comps = criterion(out, clear)
-    loss.backward()
     if sync is not None:
-        sync.all_reduce()
+        sync.begin_step()
+    loss = comps = None
+    if not empty:
+        hazy, clear = hazy.to(device), clear.to(device)
+        out = model(hazy)
+        loss, comps = criterion(out, clear)
+        loss.backward()
+    if sync is not None:
+        sync.finish()
     optimizer.step()
+    if empty:
+        return None
     return {"loss": loss.detach(), "l1": comps["l1"].detach()}
 
 
-def synthetic_loader(batch_size: int, size, steps: int, seed: int = 42, rank: int = 0) -> Iterator[Dict]:
-    """Foggy/clear pairs from the reference's fog model I = J*t + A*(1-t) (utils/helpers.py:241-258)."""
-    import torch.nn.functional as F
-    h, w = (size, size) if isinstance(size, int) else size
-    g = torch.Generator().manual_seed(seed + 1000 * rank)
-    xs = torch.linspace(0, 1, w).view(1, w)
-    ys = torch.linspace(0, 1, h).view(h, 1)
-    depth = 0.3 + 0.7 * torch.sqrt((xs - 0.5) ** 2 + (ys - 0.2) ** 2)
-    ranges = {0: ((0.1, 0.4), (0.5, 0.7)), 1: ((0.4, 0.7), (0.7, 0.9)), 2: ((0.7, 1.0), (0.8, 1.0))}
-    for _ in range(steps):
-        clear = torch.rand(batch_size, 3, h, w, generator=g)
-        clear = F.avg_pool2d(F.pad(clear, (2, 2, 2, 2), mode="reflect"), 5, 1)
-        labels = torch.randint(0, 3, (batch_size,), generator=g)
-        u = torch.rand(batch_size, 2, generator=g)
-        hazy = torch.empty_like(clear)
-        for i in range(batch_size):
-            (b0, b1), (a0, a1) = ranges[int(labels[i])]
-            t = torch.exp(-(b0 + (b1 - b0) * float(u[i, 0])) * depth)
-            hazy[i] = (clear[i] * t + (a0 + (a1 - a0) * float(u[i, 1])) * (1 - t)).clamp(0, 1)
-        yield {"hazy": hazy, "clear": clear, "intensity": labels, "name": [f"synthetic_{i}" for i in range(batch_size)]}
+# ---------------------------------------------------------------------------------------------------------------------
+# validation (device-side metrics, one read-back per epoch)
+# ---------------------------------------------------------------------------------------------------------------------
+def _finish_validation(sums: Dict[str, torch.Tensor], count: int, device) -> Dict[str, float]:
+    """Sample-weighted means; under data parallelism sums and counts are added over the ranks first."""
+    import torch.distributed as dist
+    keys = sorted(sums)
+    vec = torch.stack([sums[k].double().reshape(()) for k in keys] + [torch.tensor(float(count), dtype=torch.float64,
+                                                                                   device=device)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(vec)
+        else:
+            host = vec.cpu()
+            dist.all_reduce(host)
+            vec = host
+    host = vec.cpu().tolist()   # the epoch's one host read-back
+    n = host[-1]
+    out = {k: (v / n if n > 0 else 0.0) for k, v in zip(keys, host[:-1])}
+    out["val_samples"] = int(n)
+    return out
 
 
-def train_joint_model(config, train_loader=None, steps_per_epoch: int = 4, epochs: Optional[int] = None):
-    """train_joint.py:29 entry point (training part); returns the system and the per-epoch mean losses."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    system = build_joint_system(config, world)
-    system["classifier"].train()
+def validate_joint(system: Dict, val_loader: Iterable[Dict]) -> Dict[str, float]:
+    """train_joint.py:173-236: eval mode, classifier -> router -> JointLoss, per-image PSNR / SSIM; returns
+    {'val_loss','val_dehaze_loss','val_class_loss','val_psnr','val_ssim','val_samples'} (sample-weighted means)."""
+    dev = system["device"]
+    system["classifier"].eval()
     for m in system["models"].values():
-        m.train()
-    system["router"].train()
+        m.eval()
+    system["router"].eval()
+    sums: Dict[str, torch.Tensor] = {}
+    count = 0
+
+    def add(k, v):
+        sums[k] = v if k not in sums else sums[k] + v
+
+    with torch.no_grad():
+        for batch in val_loader:
+            hazy, clear, labels = batch["hazy"].to(dev), batch["clear"].to(dev), batch["intensity"].to(dev)
+            logits, _ = system["classifier"](hazy)
+            dehazed, _ = system["router"](hazy, logits)
+            loss, comps = system["criterion"](dehazed, clear, logits, labels)
+            n = hazy.size(0)
+            add("val_loss", loss.detach().double() * n)
+            add("val_dehaze_loss", comps["dehazing"].detach().double() * n)
+            add("val_class_loss", comps["classification"].detach().double() * n)
+            add("val_psnr", psnr_batch(dehazed, clear).double().sum())
+            add("val_ssim", ssim_batch(dehazed, clear).double().sum())
+            count += n
+    if not sums:
+        return {"val_loss": 0.0, "val_dehaze_loss": 0.0, "val_class_loss": 0.0, "val_psnr": 0.0, "val_ssim": 0.0,
+                "val_samples": 0}
+    return _finish_validation(sums, count, dev)
+
+
+def validate_dehazing(model, criterion, val_loader: Iterable[Dict], level: Optional[int], device) -> Dict[str, float]:
+    """train_dehazing.py:109-166: eval mode, images of this branch's level only; returns
+    {'val_loss','val_perceptual','val_psnr','val_ssim','val_samples'}."""
+    model.eval()
+    sums: Dict[str, torch.Tensor] = {}
+    count = 0
+
+    def add(k, v):
+        sums[k] = v if k not in sums else sums[k] + v
+
+    with torch.no_grad():
+        for batch in val_loader:
+            hazy, clear = batch["hazy"], batch["clear"]
+            if level is not None:
+                keep = batch["intensity"] == level
+                if int(keep.sum()) == 0:
+                    continue
+                hazy, clear = hazy[keep], clear[keep]
+            hazy, clear = hazy.to(device), clear.to(device)
+            out = model(hazy)
+            loss, comps = criterion(out, clear)
+            n = hazy.size(0)
+            add("val_loss", loss.detach().double() * n)
+            add("val_perceptual", comps["perceptual"].detach().double() * n)
+            add("val_psnr", psnr_batch(out, clear).double().sum())
+            add("val_ssim", ssim_batch(out, clear).double().sum())
+            count += n
+    if not sums:
+        return {"val_loss": 0.0, "val_perceptual": 0.0, "val_psnr": 0.0, "val_ssim": 0.0, "val_samples": 0}
+    return _finish_validation(sums, count, torch.device(device))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# checkpoints (reference key sets) and resume
+# ---------------------------------------------------------------------------------------------------------------------
+def joint_checkpoint(system: Dict, epoch: int, val: Dict[str, float]) -> Dict:
+    """train_joint.py:272-283 / 291-302 (+ scheduler_state_dict)."""
+    return {"epoch": epoch,
+            "router_state_dict": system["router"].state_dict(),
+            "low_model_state_dict": system["models"]["low"].state_dict(),
+            "medium_model_state_dict": system["models"]["medium"].state_dict(),
+            "high_model_state_dict": system["models"]["high"].state_dict(),
+            "classifier_state_dict": system["classifier"].state_dict(),
+            "optimizer_state_dict": system["optimizer"].state_dict(),
+            "val_psnr": val["val_psnr"], "val_ssim": val["val_ssim"], "val_loss": val["val_loss"],
+            "scheduler_state_dict": system["scheduler"].state_dict()}
+
+
+def dehazing_checkpoint(model, optimizer, scheduler, epoch: int, val: Dict[str, float]) -> Dict:
+    """train_dehazing.py:196-203 / 208-215 (+ scheduler_state_dict)."""
+    return {"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+            "val_psnr": val["val_psnr"], "val_ssim": val["val_ssim"], "val_loss": val["val_loss"],
+            "scheduler_state_dict": scheduler.state_dict()}
+
+
+def find_resume_checkpoint(checkpoint_dir: str) -> Optional[str]:
+    """Latest `checkpoint_epoch_N.pth`, else `best_model.pth`, else None."""
+    best_n, best_p = -1, None
+    for p in glob.glob(os.path.join(checkpoint_dir, "checkpoint_epoch_*.pth")):
+        m = re.search(r"checkpoint_epoch_(\d+)\.pth$", p)
+        if m and int(m.group(1)) > best_n:
+            best_n, best_p = int(m.group(1)), p
+    best = os.path.join(checkpoint_dir, "best_model.pth")
+    if os.path.exists(best):
+        if best_p is None:
+            return best
+        # whichever was written later in training
+        try:
+            if torch.load(best, map_location="cpu")["epoch"] + 1 > best_n:
+                return best
+        except Exception:
+            pass
+    return best_p
+
+
+def _best_psnr_on_disk(checkpoint_dir: str) -> float:
+    p = os.path.join(checkpoint_dir, "best_model.pth")
+    if os.path.exists(p):
+        try:
+            return float(torch.load(p, map_location="cpu").get("val_psnr", 0.0))
+        except Exception:
+            return 0.0
+    return 0.0
+
+
+def _resolve_resume(resume, checkpoint_dir: str) -> Optional[str]:
+    if not resume:
+        return None
+    path = find_resume_checkpoint(checkpoint_dir) if resume is True else str(resume)
+    if path is None or not os.path.exists(path):
+        raise FileNotFoundError(f"--resume: no checkpoint to resume from ({path or checkpoint_dir})")
+    return path
+
+
+def resume_joint(system: Dict, path: str) -> int:
+    """Restore a joint checkpoint; returns the epoch to continue with."""
+    ck = torch.load(path, map_location="cpu")
+    system["router"].load_state_dict(ck["router_state_dict"])   # holds the classifier and the three branches
+    if "optimizer_state_dict" in ck:
+        system["optimizer"].load_state_dict(ck["optimizer_state_dict"])
+    if "scheduler_state_dict" in ck:
+        system["scheduler"].load_state_dict(ck["scheduler_state_dict"])
+    from .engine import invalidate_weight_cache
+    invalidate_weight_cache()
+    print(f"Resumed joint training from {path} (epoch {ck['epoch'] + 1} done)")
+    return int(ck["epoch"]) + 1
+
+
+def _warn_synthetic(config, what: str, rank: int):
+    paths = [config.get("dataset", {}).get(k) for k in ("train_path", "val_path", "test_path")]
+    if rank == 0:
+        msg = (f"{what}: no DataLoader was supplied -- training on SYNTHETIC foggy frames generated on the GPU "
+               "(data.synthetic_loader); checkpoints written by this run are trained on noise-like images.")
+        if any(paths):
+            msg += (f"  Dataset paths are configured ({[p for p in paths if p]}) but this build does not read image "
+                    "folders (data/dataset.py needs cv2, out of scope): pass train_loader= / val_loader=.")
+        warnings.warn(msg, stacklevel=3)
+
+
+def train_joint_model(config, train_loader=None, val_loader=None, steps_per_epoch: int = 4, epochs: Optional[int] = None,
+                      resume=None, val_steps: int = 2):
+    """train_joint.py:29 entry point: epochs of (train, validate, scheduler.step(val_loss), best / periodic
+    checkpoints).  `train_loader` / `val_loader`: iterables of batch dicts (re-iterated every epoch) or callables
+    epoch -> iterable; synthetic frames when None.  Returns (system, history of per-epoch dicts)."""
+    world, rank = _world_rank()
+    system = build_joint_system(config, world)
+    dev = system["device"]
+    ck_dir = config["joint_training"]["checkpoint_dir"]
     epochs = config["joint_training"]["epochs"] if epochs is None else epochs
+    start_epoch, best_val_psnr = 0, 0.0
+    path = _resolve_resume(resume, ck_dir)
+    if path is not None:
+        start_epoch = resume_joint(system, path)
+        best_val_psnr = _best_psnr_on_disk(ck_dir)
+        if system["sync"] is not None:
+            system["sync"].broadcast_parameters(system["router"])
+    if train_loader is None or val_loader is None:
+        _warn_synthetic(config, "train_joint_model", rank)
+    bs, size = config["dataset"]["batch_size"], config["dataset"]["img_size"]
+
+    def loader_for(ld, epoch, steps, seed_off):
+        if ld is None:
+            return synthetic_loader(bs, size, steps, seed=config["seed"] + seed_off + epoch, rank=rank, device=dev)
+        return ld(epoch) if callable(ld) else ld
+
     history = []
-    for epoch in range(epochs):
-        loader = train_loader if train_loader is not None else synthetic_loader(
-            config["dataset"]["batch_size"], config["dataset"]["img_size"], steps_per_epoch, seed=config["seed"] + epoch,
-            rank=rank)
+    if rank == 0:
+        os.makedirs(ck_dir, exist_ok=True)
+    for epoch in range(start_epoch, epochs):
+        system["classifier"].train()
+        for m in system["models"].values():
+            m.train()
+        system["router"].train()
         total, n = None, 0
-        for batch in loader:
+        for batch in loader_for(train_loader, epoch, steps_per_epoch, 0):
             stats = joint_train_step(system, batch)
             total = stats["loss"] if total is None else total + stats["loss"]
             n += 1
-        mean = float(total) / max(1, n)     # one host read-back per epoch
-        history.append(mean)
-        system["scheduler"].step(mean)
+        val = validate_joint(system, loader_for(val_loader, 0, val_steps, 500000))   # a fixed validation set
+        train_loss = all_reduce_mean_scalar(float(total) / max(1, n) if total is not None else 0.0, dev)
+        system["scheduler"].step(val["val_loss"])      # every rank steps on the same (rank-averaged) value
+        rec = {"epoch": epoch, "train_loss": train_loss, **val, "lr": system["optimizer"].param_groups[0]["lr"]}
+        history.append(rec)
         if rank == 0:
-            print(f"Epoch {epoch + 1}/{epochs} train_loss={mean:.4f}")
-    if rank == 0:
-        ck = config["joint_training"]["checkpoint_dir"]
-        os.makedirs(ck, exist_ok=True)
-        torch.save({"epoch": epochs, "router_state_dict": system["router"].state_dict(),
-                    "low_model_state_dict": system["models"]["low"].state_dict(),
-                    "medium_model_state_dict": system["models"]["medium"].state_dict(),
-                    "high_model_state_dict": system["models"]["high"].state_dict(),
-                    "classifier_state_dict": system["classifier"].state_dict()}, os.path.join(ck, "last_model.pth"))
+            print(f"Epoch {epoch + 1}/{epochs}:\n  Train Loss: {train_loss:.4f}\n  Val Loss: {val['val_loss']:.4f} "
+                  f"(Dehaze: {val['val_dehaze_loss']:.4f}, Class: {val['val_class_loss']:.4f})\n"
+                  f"  Val PSNR: {val['val_psnr']:.2f} dB, Val SSIM: {val['val_ssim']:.4f}")
+            if val["val_psnr"] > best_val_psnr:
+                torch.save(joint_checkpoint(system, epoch, val), os.path.join(ck_dir, "best_model.pth"))
+                print(f"Saved best model with validation PSNR: {val['val_psnr']:.2f} dB")
+            if (epoch + 1) % 5 == 0:
+                torch.save(joint_checkpoint(system, epoch, val), os.path.join(ck_dir, f"checkpoint_epoch_{epoch + 1}.pth"))
+        best_val_psnr = max(best_val_psnr, val["val_psnr"])
     return system, history
 
 
-def train_dehazing_model(config, intensity_level: str, train_loader=None, steps: int = 4):
-    """train_dehazing.py:16 entry point (training part) for one branch: Adam(lr, wd 1e-4) + DehazingLoss."""
+def train_dehazing_model(config, intensity_level: str, train_loader=None, val_loader=None, steps: int = 4,
+                         epochs: int = 1, resume=None, val_steps: int = 2, model=None):
+    """train_dehazing.py:16 entry point for one branch: Adam(lr, wd 1e-4) + ReduceLROnPlateau(patience 5) +
+    DehazingLoss, level-filtered batches, validation, best / every-5-epochs checkpoints under
+    `<dehazing.checkpoint_dir>/<level>/` (the reference runs 30 epochs, :64).  Returns (model, per-step train losses)."""
+    world, rank = _world_rank()
     device = torch.device(config["device"])
     factory = {"low": create_low_intensity_model, "medium": create_medium_intensity_model,
                "high": create_high_intensity_model}[intensity_level]
-    model = factory(config).to(device).train()
+    model = (factory(config) if model is None else model).to(device).train()
     criterion = get_dehazing_loss(config).to(device)
     optimizer = Adam(model.parameters(), lr=config["dehazing"][intensity_level]["learning_rate"], weight_decay=1e-4)
-    level = {"low": 0, "medium": 1, "high": 2}[intensity_level]
-    loader = train_loader if train_loader is not None else synthetic_loader(
-        config["dataset"]["batch_size"], config["dataset"]["img_size"], steps, seed=config["seed"])
+    scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=0.5, patience=5)
+    level = LEVELS[intensity_level]
+    ck_dir = os.path.join(config["dehazing"]["checkpoint_dir"], intensity_level)
+    sync = None
+    if world > 1:
+        sync = GradientSynchronizer(list(model.parameters()), world)
+        sync.broadcast_parameters(model)
+        sync.install()
+    start_epoch, best_val_psnr = 0, 0.0
+    path = _resolve_resume(resume, ck_dir)
+    if path is not None:
+        ck = torch.load(path, map_location="cpu")
+        model.load_state_dict(ck["model_state_dict"])
+        if "optimizer_state_dict" in ck:
+            optimizer.load_state_dict(ck["optimizer_state_dict"])
+        if "scheduler_state_dict" in ck:
+            scheduler.load_state_dict(ck["scheduler_state_dict"])
+        start_epoch, best_val_psnr = int(ck["epoch"]) + 1, _best_psnr_on_disk(ck_dir)
+        from .engine import invalidate_weight_cache
+        invalidate_weight_cache()
+        if sync is not None:
+            sync.broadcast_parameters(model)
+    if train_loader is None or val_loader is None:
+        _warn_synthetic(config, f"train_dehazing_model[{intensity_level}]", rank)
+    bs, size = config["dataset"]["batch_size"], config["dataset"]["img_size"]
+
+    def loader_for(ld, epoch, nsteps, seed_off):
+        if ld is None:
+            return synthetic_loader(bs, size, nsteps, seed=config["seed"] + seed_off + epoch, rank=rank, device=device)
+        return ld(epoch) if callable(ld) else ld
+
     losses = []
-    for batch in loader:
-        st = dehazing_train_step(model, criterion, optimizer, batch, level, device)
-        if st is not None:
-            losses.append(st["loss"])
+    if rank == 0:
+        os.makedirs(ck_dir, exist_ok=True)
+    try:
+        for epoch in range(start_epoch, epochs):
+            model.train()
+            for batch in loader_for(train_loader, epoch, steps, 0):
+                st = dehazing_train_step(model, criterion, optimizer, batch, level, device, sync=sync)
+                if st is not None:
+                    losses.append(st["loss"])
+            val = validate_dehazing(model, criterion, loader_for(val_loader, 0, val_steps, 500000), level, device)
+            scheduler.step(val["val_loss"])
+            if rank == 0:
+                print(f"Epoch {epoch + 1}/{epochs}:\n  Val Loss: {val['val_loss']:.4f}, Val PSNR: {val['val_psnr']:.2f}, "
+                      f"Val SSIM: {val['val_ssim']:.4f}")
+                if val["val_psnr"] > best_val_psnr:
+                    torch.save(dehazing_checkpoint(model, optimizer, scheduler, epoch, val),
+                               os.path.join(ck_dir, "best_model.pth"))
+                    print(f"Saved best model with validation PSNR: {val['val_psnr']:.2f} dB")
+                if (epoch + 1) % 5 == 0:
+                    torch.save(dehazing_checkpoint(model, optimizer, scheduler, epoch, val),
+                               os.path.join(ck_dir, f"checkpoint_epoch_{epoch + 1}.pth"))
+            best_val_psnr = max(best_val_psnr, val["val_psnr"])
+    finally:
+        if sync is not None:
+            sync.uninstall()
     return model, [float(x) for x in losses]
+
+
+def evaluate_joint_model(config, test_loader=None, steps: int = 2, use_lpips: bool = True):
+    """evaluation/evaluate.py:94-177 (image-quality part): load the joint checkpoint if present, route every test
+    batch, accumulate PSNR / SSIM / LPIPS per intensity category on the device, print and save
+    `<evaluation.results_dir>/joint_model_results.json` (schema of evaluation/metrics.py:117-124)."""
+    from .metrics import CATEGORY_BY_LABEL, ImageQualityMetrics
+    world, rank = _world_rank()
+    system = build_joint_system(config, 1)
+    dev = system["device"]
+    ck = os.path.join(config["joint_training"]["checkpoint_dir"], "best_model.pth")
+    if os.path.exists(ck):
+        c = torch.load(ck, map_location="cpu")
+        system["router"].load_state_dict(c["router_state_dict"])
+        print(f"Loaded joint model from {ck}")
+    else:
+        print(f"Joint checkpoint {ck} not found. Using the individually loaded / random weights.")
+    system["classifier"].eval()
+    for m in system["models"].values():
+        m.eval()
+    system["router"].eval()
+    metrics = ImageQualityMetrics(device=dev, use_lpips=use_lpips)
+    if test_loader is None:
+        _warn_synthetic(config, "evaluate_joint_model", rank)
+        test_loader = synthetic_loader(config["dataset"]["batch_size"], config["dataset"]["img_size"], steps,
+                                       seed=config["seed"] + 900000, rank=rank, device=dev)
+    with torch.no_grad():
+        for batch in test_loader:
+            hazy, clear = batch["hazy"].to(dev), batch["clear"].to(dev)
+            logits, _ = system["classifier"](hazy)
+            dehazed, _ = system["router"](hazy, logits)
+            cats = [CATEGORY_BY_LABEL.get(int(i), "high_intensity") for i in batch["intensity"].tolist()]
+            metrics.add_batch(dehazed, clear, cats)
+    results = metrics.print_results()
+    out_dir = config.get("evaluation", {}).get("results_dir", "results")
+    metrics.save_results(os.path.join(out_dir, "joint_model_results.json"))
+    return results

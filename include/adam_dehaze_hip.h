@@ -359,6 +359,46 @@ int adh_bilinear(void* stream, const float* x, int x_cs, int N, int H, int W, in
 int adh_bilinear_bwd(void* stream, const float* g, int g_cs, int N, int H, int W, int C, int OH, int OW,
                      int align_corners, float* gx, int gx_cs);
 
+/* ---- training loop / evaluation harness around the hot path (csrc/train_io.hip) ------------------------------ */
+/* Multi-tensor Adam: ONE launch updates every listed tensor (training/train_joint.py:86-90,153-154;
+ * training/train_dehazing.py:52-57,95-96 call torch.optim.Adam.step, one ATen op group per tensor).
+ * table_dev[i] describes tensor i (device pointers; `step` = updates taken before this call; `repeats` = how many
+ * times the reference lists the parameter, train_joint.py:81-84); chunks_dev holds nchunks pairs (tensor index, chunk
+ * index), a chunk being adh_adam_chunk_elems() consecutive floats.  g is read as g*grad_scale (1/world for summed
+ * data-parallel gradients).  dup_mode 0: `repeats` consecutive full updates (torch's single-tensor loop: the CPU path
+ * and every torch < 2.0); 1: torch >= 2.0's foreach form on CUDA (see train_io.hip).  max_repeats <= 4. */
+typedef struct adh_adam_tensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+    int32_t step;
+    int32_t repeats;
+} adh_adam_tensor;
+int adh_adam_chunk_elems(void);
+int adh_adam_multi(void* stream, const adh_adam_tensor* table_dev, const int32_t* chunks_dev, int nchunks, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, int dup_mode,
+                   int max_repeats);
+/* Synthetic fog on NCHW images, per-image beta / airlight: hazy = clip(clear*t + A*(1-t), 0, 1),
+ * t = exp(-beta*(0.3 + 0.7*sqrt((x-0.5)^2 + (y-0.2)^2))) on the unit grid (utils/helpers.py:241-258, transmission in
+ * float64 as numpy evaluates it). */
+int adh_apply_fog(void* stream, const float* clear_nchw, const float* beta, const float* airlight, int N, int H, int W,
+                  float* hazy_nchw);
+/* Per-image PSNR over per_image = 3*H*W elements (skimage peak_signal_noise_ratio as called at
+ * evaluation/metrics.py:27 and training/train_joint.py:217); partial: double[N * adh_psnr_num_blocks(per_image)];
+ * mse (optional) and psnr: float[N]. */
+int adh_psnr_num_blocks(int64_t per_image);
+int adh_psnr(void* stream, const float* pred, const float* target, int N, int64_t per_image, float data_range,
+             double* partial, int nblk, float* mse, float* psnr);
+/* Per-image SSIM of the channel-mean grayscale images with skimage's defaults (7x7 uniform window, K1 .01, K2 .03,
+ * sample covariance, mean over the image cropped by 3 px) as called at evaluation/metrics.py:29-32 and
+ * training/train_joint.py:221-224; partial: double[N * adh_ssim_num_blocks(H, W)]; ssim: float[N].
+ * ADH_E_UNSUPPORTED when H or W < 7 (skimage raises there too). */
+int adh_ssim_num_blocks(int H, int W);
+int adh_ssim_gray(void* stream, const float* pred_nchw, const float* target_nchw, int N, int H, int W, float data_range,
+                  double* partial, int nblk, float* ssim);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,11 +4,18 @@ the hot path run on the HIP engine; the others (dataset preprocessing, classifie
 evaluation) are outside this build's scope and say so.
 
     python main.py --mode train_joint --config config/config.yaml
+    python main.py --mode train_joint --resume                     # continue from the latest checkpoint
     torchrun --nproc-per-node 8 main.py --mode train_joint        # data-parallel over RCCL
+
+`--resume` is the reference's flag (main.py:50-51 parses it and never reads it); here it restores model, optimiser,
+scheduler, epoch and best-PSNR from the latest checkpoint of the mode's checkpoint directory (or from the file given
+as its optional value).  Image folders are not read by this build (data/dataset.py needs cv2): `--data_dir` is recorded
+in the config like the reference does, and the drivers then say loudly that they train on synthetic frames.
 """
 import argparse
 import os
 import random
+import warnings
 
 import numpy as np
 import torch
@@ -18,31 +25,37 @@ import yaml
 def parse_args():
     p = argparse.ArgumentParser(description="Adaptive fog intensity dehazing framework (MI355X build)")
     p.add_argument("--config", type=str, default="config/config.yaml")
-    p.add_argument("--mode", type=str, required=True,
+    p.add_argument("--mode", type=str, default="train_all",
                    choices=["preprocess", "train_classifier", "train_dehazing", "train_joint", "train_all", "evaluate", "demo"])
+    p.add_argument("--exp_name", type=str, default=None)
     p.add_argument("--data_dir", type=str, default=None)
     p.add_argument("--device", type=str, default=None)
+    p.add_argument("--resume", nargs="?", const=True, default=None,
+                   help="resume training from the latest checkpoint (or from the given checkpoint file)")
     p.add_argument("--seed", type=int, default=None)
-    p.add_argument("--resume", type=str, default=None)
-    p.add_argument("--exp_name", type=str, default="default")
     p.add_argument("--epochs", type=int, default=None, help="override the configured number of epochs")
     return p.parse_args()
 
 
 def seed_everything(seed):
+    """utils/helpers.py:10-19."""
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
 
 
 def main():
     args = parse_args()
     with open(args.config) as f:
         config = yaml.safe_load(f)
-    if args.data_dir:
-        for k in ("train_path", "val_path", "test_path"):
-            config["dataset"][k] = args.data_dir
+    if args.data_dir:   # main.py:66-69
+        config["dataset"]["train_path"] = os.path.join(args.data_dir, "train")
+        config["dataset"]["val_path"] = os.path.join(args.data_dir, "val")
+        config["dataset"]["test_path"] = os.path.join(args.data_dir, "test")
+        warnings.warn(f"--data_dir {args.data_dir}: this build does not read image folders (cv2 dataset code is out of "
+                      "scope); the training modes fall back to synthetic foggy frames and say so.")
     if args.device:
         config["device"] = args.device
     if args.seed:
@@ -54,21 +67,29 @@ def main():
         torch.cuda.set_device(local)
         config["device"] = f"cuda:{local}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("ADH_DIST_BACKEND", "nccl")   # nccl = RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     seed_everything(config["seed"])
     from adam_dehaze_amd import train as T
     if args.mode == "train_joint":
-        T.train_joint_model(config, epochs=args.epochs)
+        T.train_joint_model(config, epochs=args.epochs, resume=args.resume)
     elif args.mode == "train_dehazing":
-        for level in ("low", "medium", "high"):
-            T.train_dehazing_model(config, level)
+        for level in ("low", "medium", "high"):   # train_dehazing.py:216-232
+            T.train_dehazing_model(config, level, epochs=args.epochs or 30, resume=args.resume)
+    elif args.mode == "evaluate":
+        # evaluate.py:464-540 runs image-quality evaluation of the joint model, then object detection on dehazed frames;
+        # the detector stage needs torchvision detection weights that are not in this image
+        T.evaluate_joint_model(config)
+        print("object-detection evaluation (models/detection.py) is outside this build's scope: skipped")
     elif args.mode == "demo":
-        from adam_dehaze_amd.routing import create_router
         system = T.build_joint_system(config)
         system["router"].eval()
-        batch = next(T.synthetic_loader(2, config["dataset"]["img_size"], 1, seed=config["seed"]))
+        batch = next(T.synthetic_loader(2, config["dataset"]["img_size"], 1, seed=config["seed"], device=config["device"]))
         with torch.no_grad():
-            out, aux = system["router"](batch["hazy"].to(config["device"]))
+            out, aux = system["router"](batch["hazy"])
         print("dehazed", tuple(out.shape), "weights", aux["weights"].cpu().tolist())
     else:
         raise SystemExit(f"mode '{args.mode}' is outside the hot path this build covers (see DESIGN.md section 7)")

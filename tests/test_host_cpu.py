@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 _CTYPE = {"void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int32_t*": ctypes.c_void_p, "int64_t*": ctypes.c_void_p,
           "int": ctypes.c_int32, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
-          "double": ctypes.c_double}
+          "double": ctypes.c_double, "double*": ctypes.c_void_p, "adh_adam_tensor*": ctypes.c_void_p}
 
 
 def test_ctypes_signatures_match_header():
@@ -73,6 +73,10 @@ def test_struct_layouts_match_header_field_order():
     assert names == got, (names, got)
     assert ctypes.sizeof(H.ConvDesc) == 7 * 8 + 26 * 4
     assert ctypes.sizeof(H.WLayout) == 9 * 4
+    body = re.search(r"typedef struct adh_adam_tensor \{(.*?)\} adh_adam_tensor;", header, flags=re.S).group(1)
+    names = [re.split(r"[\s*]+", d.strip())[-1] for d in body.split(";") if d.strip()]
+    assert names == [f[0] for f in H.AdamTensor._fields_], names
+    assert ctypes.sizeof(H.AdamTensor) == 4 * 8 + 8 + 2 * 4
 
 
 def test_state_dict_keys_and_seeded_init_match_reference():
@@ -174,3 +178,66 @@ def test_counted_wait_kernels_have_no_scratch_traffic(tmp_path):
             assert "s" not in seq[seq.index("m"):seq.rindex("m")], name
         else:
             assert "s" not in seq, name
+
+
+def test_adam_state_dict_layout_matches_torch():
+    """optim.Adam.state_dict() uses torch.optim.Adam's layout (duplicates under the index of their last occurrence,
+    as recorded from torch in adam_dup_foreach.npz) and round-trips through torch.optim.Adam.load_state_dict."""
+    from adam_dehaze_amd.optim import Adam
+    rec = load_golden("adam_dup_foreach")
+    a, b, c = (torch.nn.Parameter(torch.randn(s)) for s in ((5, 4), (7,), (33,)))
+    listed = [a, b, a, c, c, c]
+    opt = Adam(listed, lr=5e-5, weight_decay=1e-4)
+    for p, n in ((a, 6), (b, 3), (c, 9)):
+        opt.state[id(p)] = {"step": n, "m": torch.randn_like(p), "v": torch.rand_like(p)}
+    sd = opt.state_dict()
+    assert sd["param_groups"][0]["params"] == rec["state_params"].tolist()
+    assert [float(sd["state"][k]["step"]) for k in sorted(sd["state"])] == rec["state_steps"].tolist()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        topt = torch.optim.Adam(listed, lr=1.0)
+        topt.load_state_dict(sd)                      # torch accepts our layout ...
+        back = topt.state_dict()
+    opt2 = Adam(listed, lr=1.0)
+    opt2.load_state_dict(back)                        # ... and we accept torch's
+    assert opt2.param_groups[0]["lr"] == 5e-5
+    for p in (a, b, c):
+        assert opt2.state[id(p)]["step"] == opt.state[id(p)]["step"]
+        assert torch.equal(opt2.state[id(p)]["m"], opt.state[id(p)]["m"])
+    with pytest.raises(ValueError):
+        Adam([a], duplicates="nope")
+
+
+def test_cli_keeps_the_reference_flags():
+    """main.py:29-56 of the reference: same flag names; --resume works bare (store_true there) or with a path."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("adh_main", os.path.join(ROOT, "main.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import sys
+    old = sys.argv
+    try:
+        sys.argv = ["main.py", "--mode", "train_joint", "--resume", "--data_dir", "/d", "--device", "cuda:0", "--seed", "3",
+                    "--exp_name", "e", "--config", "c.yaml"]
+        a = mod.parse_args()
+        assert a.resume is True and a.data_dir == "/d" and a.seed == 3
+        sys.argv = ["main.py", "--mode", "train_dehazing", "--resume", "/x/ck.pth"]
+        assert mod.parse_args().resume == "/x/ck.pth"
+        sys.argv = ["main.py"]
+        assert mod.parse_args().mode == "train_all" and mod.parse_args().resume is None
+    finally:
+        sys.argv = old
+
+
+def test_resume_checkpoint_discovery(tmp_path):
+    from adam_dehaze_amd.train import find_resume_checkpoint
+    d = str(tmp_path)
+    assert find_resume_checkpoint(d) is None
+    torch.save({"epoch": 4}, os.path.join(d, "checkpoint_epoch_5.pth"))
+    torch.save({"epoch": 9}, os.path.join(d, "checkpoint_epoch_10.pth"))
+    assert find_resume_checkpoint(d).endswith("checkpoint_epoch_10.pth")
+    torch.save({"epoch": 11, "val_psnr": 20.0}, os.path.join(d, "best_model.pth"))
+    assert find_resume_checkpoint(d).endswith("best_model.pth")       # written later in training than epoch 10
+    torch.save({"epoch": 7, "val_psnr": 20.0}, os.path.join(d, "best_model.pth"))
+    assert find_resume_checkpoint(d).endswith("checkpoint_epoch_10.pth")

@@ -199,3 +199,55 @@ def test_psnr_and_synthetic_batch():
     a = torch.zeros(1, 3, 4, 4)
     b = torch.full((1, 3, 4, 4), 0.1)
     assert abs(R.psnr(a, b) - 20.0) < 1e-4
+
+
+def test_adam_duplicate_params_foreach_form():
+    """torch >= 2.0's CUDA default (_multi_tensor_adam) with duplicated list entries: pinned by
+    adam_dup_foreach.npz (tools/gen_golden_adam.py, torch.optim.Adam(foreach=True)); differs from the sequential form."""
+    rec = load_golden("adam_dup_foreach")
+    seq = load_golden("adam_dup")
+    assert np.array_equal(rec["w_dup0"], seq["w_dup0"]) and np.array_equal(rec["g_dup1"], seq["g_dup1"])   # same scenario
+    st = {k: (t(rec[f"w_{k}0"]), torch.zeros_like(t(rec[f"w_{k}0"])), torch.zeros_like(t(rec[f"w_{k}0"])), r)
+          for k, r in (("dup", 2), ("single", 1), ("tri", 3))}
+    for step in range(3):
+        for k, (w, m, v, r) in st.items():
+            R.adam_step_foreach(w, t(rec[f"g_{k}{step}"]), m, v, step=r * step, lr=5e-5, weight_decay=1e-4, repeats=r)
+            assert max_abs(w, rec[f"w_{k}{step + 1}"]) < 1e-7, (k, step)
+    # the two semantics are really different (ADVICE r1: ~8 % of an update) -- and identical without duplicates
+    assert max_abs(t(rec["w_dup3"]), seq["w_dup3"]) > 1e-6
+    assert max_abs(t(rec["w_single3"]), seq["w_single3"]) < 1e-7
+
+
+def test_image_metrics_restatements():
+    """PSNR / SSIM restatements (UNPINNED: skimage absent) against first-principles evaluations: the float64 window
+    definition of SSIM on every interior pixel, and PSNR of a constant offset."""
+    g = torch.Generator().manual_seed(1)
+    a = torch.rand(2, 3, 18, 25, generator=g)
+    b = (a + 0.05 * torch.randn(a.shape, generator=g)).clamp(0, 1)
+    got = R.ssim_per_image(b, a)
+    for i in range(2):
+        g1, g2 = a[i].mean(0).double().numpy(), b[i].mean(0).double().numpy()
+        vals = []
+        for y in range(3, 15):
+            for x in range(3, 22):
+                w1, w2 = g1[y - 3:y + 4, x - 3:x + 4], g2[y - 3:y + 4, x - 3:x + 4]
+                ux, uy = w1.mean(), w2.mean()
+                vx, vy = w1.var(ddof=1), w2.var(ddof=1)
+                vxy = ((w1 - ux) * (w2 - uy)).sum() / 48
+                vals.append((2 * ux * uy + 1e-4) * (2 * vxy + 9e-4) / ((ux * ux + uy * uy + 1e-4) * (vx + vy + 9e-4)))
+        assert abs(float(got[i]) - float(np.mean(vals))) < 1e-6      # float32 channel mean vs float64: ~1e-8
+    assert float(R.ssim_per_image(a, a).min()) > 1 - 1e-12
+    c = torch.full((1, 3, 8, 8), 0.25)
+    assert abs(float(R.psnr_per_image(c + 0.1, c)) - 20.0) < 1e-5
+
+
+def test_fog_restatement_properties():
+    """apply_fog (UNPINNED restatement of helpers.py:241-258): beta = 0 leaves the image, A = 1 with huge beta
+    saturates to 1, and the centre of the depth map (x=.5, y=.2) is the least foggy pixel."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 21, 41, generator=g) * 0.5
+    assert torch.equal(R.apply_fog(x, [0.0, 0.0], [0.7, 0.9]), x)
+    assert float(R.apply_fog(x, [1e3, 1e3], [1.0, 1.0]).min()) == 1.0
+    f = R.apply_fog(torch.zeros(1, 3, 21, 41), [1.0], [1.0])[0, 0]
+    yy, xx = np.unravel_index(int(f.argmin()), f.shape)
+    assert (yy, xx) == (4, 20)     # y = 0.2 * 20, x = 0.5 * 40

@@ -1,3 +1,4 @@
+# dev probe (GPU box only, run by hand): does the weight-gradient kernel overlap with BN passes on a second stream?
 import sys, torch
 sys.path.insert(0, '/root/repo')
 from adam_dehaze_amd import _hip as H

@@ -1,3 +1,4 @@
+# dev probe (GPU box only, run by hand): which layers move when one ReLU flips under Winograd rounding in the tiny fixtures
 import sys, os, torch
 sys.path.insert(0, '.')
 import adam_dehaze_amd as A
