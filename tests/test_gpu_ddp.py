@@ -1,0 +1,77 @@
+"""Two data-parallel ranks of the REAL training step on one MI355X: each rank runs
+CORUN-Complex (base 16) in train mode on its own shard with ADH_DIST_BACKEND-style gloo rendezvous, gradients go through
+GradientSynchronizer's flat buckets, launched from inside Engine.backward().  Checked against the oracle run shard by
+shard: synchronized gradients = mean of the shard gradients, BatchNorm buffers = each replica's own ("replica-BN"),
+replicas identical after broadcast / Adam steps / a plateau-triggered LR change, buckets in flight before backward
+returns.  The ranks are fresh child processes (never a re-exec of this one)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_training_step_matches_shardwise_oracle(tmp_path):
+    world = 2
+    port = 31000 + os.getpid() % 2000
+    env = dict(os.environ, ADH_WINOGRAD="0", HSA_ENABLE_IPC_MODE_LEGACY="0")   # direct kernels: reference summation order
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_worker.py"), str(r), str(world), str(port),
+                               str(tmp_path)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    recs = [torch.load(tmp_path / f"rank{r}.pt", map_location="cpu") for r in range(world)]
+    # replicas were seeded differently and broadcast from rank 0
+    for k, v in recs[0]["sd0"].items():
+        assert torch.equal(v, recs[1]["sd0"][k]), k
+    # oracle, shard by shard
+    hazy, clear, _ = R.synthetic_batch(2 * world, 32, 48, seed=77)
+    shard_grads, shard_bn = [], []
+    for r in range(world):
+        sd = {k: v.clone() for k, v in recs[0]["sd0"].items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+        out = R.high_forward(hazy[2 * r:2 * r + 2], sd, training=True)
+        loss = F.l1_loss(out, clear[2 * r:2 * r + 2])
+        loss.backward()
+        assert abs(float(loss) - recs[r]["loss"]) < 1e-5
+        shard_grads.append({k: sd[k].grad for k in recs[0]["grads"]})
+        shard_bn.append({k: v.detach() for k, v in sd.items() if "running" in k})
+    for k in recs[0]["grads"]:
+        mean = sum(g[k] for g in shard_grads) / world
+        assert torch.equal(recs[0]["grads"][k], recs[1]["grads"][k]), k           # bit-identical on both ranks
+        scale = max(float(mean.abs().max()), 1e-8)
+        if k.startswith("decoder") and k.endswith(".0.bias"):
+            continue      # ConvTranspose bias feeding train-mode BN: true gradient 0, the oracle holds rounding noise
+        assert float((recs[0]["grads"][k] - mean).abs().max()) < 5e-3 * scale + 2e-7, k
+    for r in range(world):
+        for k, v in shard_bn[r].items():
+            assert float((recs[r]["bn"][k] - v).abs().max()) < 1e-5, (r, k)       # replica-BN: each rank its own shard
+    assert any(not torch.equal(recs[0]["bn"][k], recs[1]["bn"][k]) for k in recs[0]["bn"])
+    # after three optimizer steps and a rank-averaged plateau decision: identical replicas, identical learning rate
+    assert recs[0]["lr"] == recs[1]["lr"] and recs[0]["lr"] < 1e-3
+    for k, v in recs[0]["params"].items():
+        assert torch.equal(v, recs[1]["params"][k]), k
+        assert not torch.equal(v, recs[0]["sd0"][k]) or v.numel() == 0 or k.endswith(".0.bias"), k
+    # several buckets, rebuilt in observed order after step 0, and in flight before backward returned from step 1 on
+    for r in range(world):
+        assert recs[r]["nbuckets"][0] >= 3 and recs[r]["in_arena"]
+        assert recs[r]["order"][1] == recs[r]["order"][2] and recs[r]["order"][0] != recs[r]["order"][1]
+        assert recs[r]["early"][1] >= recs[r]["nbuckets"][1] - 1 and recs[r]["early"][2] >= 1
+    assert recs[0]["order"][1] == recs[1]["order"][1]

@@ -1,0 +1,408 @@
+"""Every kernel family of the headline step at the BASELINE.json sizes.
+
+The CPU oracle cannot run 8 x 512 x 1024 tensors, so these tests use size-independent checks, all through the C ABI:
+  * crops: windows of the full-size result (first / last image, corners, interior) against the fp64 definition
+    evaluated with torch on the CPU for just that window (F.conv2d / F.conv_transpose2d on the crop + halo);
+  * linearity: op(a + b) = op(a) + op(b) over the whole tensor;
+  * weight gradients: the whole batch in one launch against the sum of per-image launches (different split
+    geometry), and rank-one inputs x = a(n,y,x)*u(c), g = b(n,y,x)*v(o), whose exact gradient u v^T * corr(a, b)
+    needs only 16 scalar correlations in fp64;
+  * BatchNorm (train mode, P = 4.2 M pixels x 8 images): mean / var / normalised output / d-gamma / d-beta against fp64
+    reductions of the raw convolution output done with torch on the GPU;
+  * CBAM at HW = 524 288: forward and backward against an fp64 torch restatement of base_model.py:43-78;
+  * whole models at config 3 (Medium, bs 16, train step) and config 5 (Complex, 4 x 1024 x 2048, eval): range,
+    determinism, batch independence in eval mode, finite and reproducible loss.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import adam_dehaze_amd as A
+from adam_dehaze_amd import _hip as H
+from adam_dehaze_amd.engine import Act, BNState, Engine
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N, HH, WW = 8, 512, 1024
+
+
+def _eng():
+    return Engine(torch.device(DEV), record=False)
+
+
+def _randn(*shape, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return torch.randn(*shape, generator=g, device=DEV)
+
+
+def _nchw64(t_nhwc):
+    return t_nhwc.permute(2, 0, 1)[None].cpu().double()
+
+
+def _check_windows(got, windows, ref_fn, scale, tol=1e-5):
+    """got: NHWC result; windows: (n, y0, y1, x0, x1); ref_fn(n, y0, y1, x0, x1) -> fp64 [h, w, C] on the CPU."""
+    for (n, y0, y1, x0, x1) in windows:
+        want = ref_fn(n, y0, y1, x0, x1)
+        have = got[n, y0:y1, x0:x1].cpu().double()
+        assert have.shape == want.shape, (have.shape, want.shape)
+        err = float((have - want).abs().max())
+        assert err < tol * scale, (n, y0, x0, err, scale)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (a) convolution kernels at 8 x 512 x 1024
+# ---------------------------------------------------------------------------------------------------------------------
+def test_wino43_data_gradient_full_size():
+    """conv_wino43_kernel in the data-gradient direction (3x3 s1, 96 -> 96, 8 x 512 x 1024): gx = conv_transpose(g, w)."""
+    C = 96
+    eng = _eng()
+    w = (_randn(C, C, 3, 3, seed=1) / (9 * C) ** 0.5)
+    g1, g2 = _randn(N, HH, WW, C, seed=2), _randn(N, HH, WW, C, seed=3)
+    plans = eng._launch_plan("conv", 3, 1, 1, w, "dgrad")
+    a, b = torch.empty_like(g1), torch.empty_like(g1)
+    eng._run_gather(plans, Act(g1), a, C, w)
+    eng._run_gather(plans, Act(g2), b, C, w)
+    a += b
+    g1 += g2
+    eng._run_gather(plans, Act(g1), b, C, w)          # b = dgrad(g1 + g2)
+    torch.cuda.synchronize()
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) < 2e-5 * scale
+    wc = w.cpu().double()
+
+    def ref(n, y0, y1, x0, x1):
+        ys, ye, xs, xe = max(y0 - 2, 0), min(y1 + 2, HH), max(x0 - 2, 0), min(x1 + 2, WW)
+        r = F.conv_transpose2d(_nchw64(g1[n, ys:ye, xs:xe]), wc, padding=1)[0].permute(1, 2, 0)
+        return r[y0 - ys:y1 - ys, x0 - xs:x1 - xs]
+    _check_windows(b, [(7, 472, 512, 960, 1024), (0, 0, 40, 0, 64), (4, 250, 290, 500, 564)], ref, scale)
+
+
+def test_wino32_stride2_conv_forward_and_data_gradient_full_size():
+    """conv_wino32_kernel: Conv2d k4 s2 p1 96 -> 192 on 8 x 512 x 1024 (four input-parity classes accumulated in the
+    transformed domain) and its data gradient (four output-parity launches of 2x2-tap forms)."""
+    Ci, Co = 96, 192
+    eng = _eng()
+    w = (_randn(Co, Ci, 4, 4, seed=4) / (16 * Ci) ** 0.5)
+    x1, x2 = _randn(N, HH, WW, Ci, seed=5), _randn(N, HH, WW, Ci, seed=6)
+    OH, OW = HH // 2, WW // 2
+    plans = eng._launch_plan("conv", 4, 2, 1, w, "fwd")
+    y1, y2 = torch.empty(N, OH, OW, Co, device=DEV), torch.empty(N, OH, OW, Co, device=DEV)
+    eng._run_gather(plans, Act(x1), y1, Co, w)
+    eng._run_gather(plans, Act(x2), y2, Co, w)
+    y1 += y2
+    x1 += x2
+    eng._run_gather(plans, Act(x1), y2, Co, w)
+    torch.cuda.synchronize()
+    scale = float(y2.abs().max())
+    assert float((y1 - y2).abs().max()) < 2e-5 * scale
+    wc = w.cpu().double()
+
+    def ref_fwd(n, y0, y1_, x0, x1_):
+        # output rows [y0, y1) read input rows [2 y0 - 1, 2 y1 + 1): explicit zero padding where that leaves the image
+        ys, ye, xs, xe = 2 * y0 - 1, 2 * y1_ + 1, 2 * x0 - 1, 2 * x1_ + 1
+        crop = x1[n, max(ys, 0):min(ye, HH), max(xs, 0):min(xe, WW)]
+        c = F.pad(_nchw64(crop), (max(-xs, 0), max(xe - WW, 0), max(-ys, 0), max(ye - HH, 0)))
+        return F.conv2d(c, wc, stride=2)[0].permute(1, 2, 0)
+    _check_windows(y2, [(7, 236, 256, 480, 512), (0, 0, 20, 0, 32), (3, 100, 120, 300, 332)], ref_fwd, scale)
+    del x2, y1
+    # data gradient: gx = conv_transpose2d(g, w, stride 2, padding 1)
+    g = _randn(N, OH, OW, Co, seed=7)
+    gx = torch.empty(N, HH, WW, Ci, device=DEV)
+    eng._run_gather(eng._launch_plan("conv", 4, 2, 1, w, "dgrad"), Act(g), gx, Ci, w)
+    torch.cuda.synchronize()
+    gscale = float(gx.abs().max())
+
+    def ref_dgrad(n, y0, y1_, x0, x1_):
+        # output (full-res) rows [y0, y1), y0 / y1 even: input rows [y0/2 - 1, y1/2 + 2) cover every contributing tap
+        iys, iye, ixs, ixe = max(y0 // 2 - 1, 0), min(y1_ // 2 + 2, OH), max(x0 // 2 - 1, 0), min(x1_ // 2 + 2, OW)
+        r = F.conv_transpose2d(_nchw64(g[n, iys:iye, ixs:ixe]), wc, stride=2, padding=1)[0].permute(1, 2, 0)
+        return r[y0 - 2 * iys:y1_ - 2 * iys, x0 - 2 * ixs:x1_ - 2 * ixs]
+    _check_windows(gx, [(7, 472, 512, 960, 1024), (0, 0, 40, 0, 64), (5, 200, 240, 400, 464)], ref_dgrad, gscale)
+
+
+def test_wino32_transposed_conv_forward_and_data_gradient_full_size():
+    """conv_wino32_kernel: ConvTranspose2d k4 s2 p1 384 -> 96 from 8 x 256 x 512 to 8 x 512 x 1024 (decoder.1.0 of the
+    headline model, four output-parity classes) and its data gradient (a k4 s2 convolution of the output gradient)."""
+    Ci, Co = 384, 96
+    IH, IW = HH // 2, WW // 2
+    eng = _eng()
+    w = (_randn(Ci, Co, 4, 4, seed=8) / (4 * Ci) ** 0.5)
+    x = _randn(N, IH, IW, Ci, seed=9)
+    y = torch.empty(N, HH, WW, Co, device=DEV)
+    eng._run_gather(eng._launch_plan("convT", 4, 2, 1, w, "fwd"), Act(x), y, Co, w)
+    torch.cuda.synchronize()
+    scale = float(y.abs().max())
+    wc = w.cpu().double()
+
+    def ref_fwd(n, y0, y1_, x0, x1_):
+        iys, iye, ixs, ixe = max(y0 // 2 - 1, 0), min(y1_ // 2 + 2, IH), max(x0 // 2 - 1, 0), min(x1_ // 2 + 2, IW)
+        r = F.conv_transpose2d(_nchw64(x[n, iys:iye, ixs:ixe]), wc, stride=2, padding=1)[0].permute(1, 2, 0)
+        return r[y0 - 2 * iys:y1_ - 2 * iys, x0 - 2 * ixs:x1_ - 2 * ixs]
+    _check_windows(y, [(7, 488, 512, 992, 1024), (0, 0, 24, 0, 32), (2, 300, 324, 600, 632)], ref_fwd, scale)
+    # linearity in the input (scaling is exact in fp32 for a power of two: only the summation order may differ)
+    y2 = torch.empty_like(y)
+    x2 = _randn(N, IH, IW, Ci, seed=10)
+    eng._run_gather(eng._launch_plan("convT", 4, 2, 1, w, "fwd"), Act(x2), y2, Co, w)
+    y += y2
+    x += x2
+    eng._run_gather(eng._launch_plan("convT", 4, 2, 1, w, "fwd"), Act(x), y2, Co, w)
+    torch.cuda.synchronize()
+    assert float((y - y2).abs().max()) < 2e-5 * float(y2.abs().max())
+    del x2, y2
+    # data gradient: gx = conv2d(g, w viewed as [Cin(out), Cout(in), 4, 4], stride 2, padding 1)
+    g = _randn(N, HH, WW, Co, seed=11)
+    gx = torch.empty(N, IH, IW, Ci, device=DEV)
+    eng._run_gather(eng._launch_plan("convT", 4, 2, 1, w, "dgrad"), Act(g), gx, Ci, w)
+    torch.cuda.synchronize()
+    gscale = float(gx.abs().max())
+
+    def ref_dgrad(n, y0, y1_, x0, x1_):
+        ys, ye, xs, xe = 2 * y0 - 1, 2 * y1_ + 1, 2 * x0 - 1, 2 * x1_ + 1
+        crop = g[n, max(ys, 0):min(ye, HH), max(xs, 0):min(xe, WW)]
+        c = F.pad(_nchw64(crop), (max(-xs, 0), max(xe - WW, 0), max(-ys, 0), max(ye - HH, 0)))
+        return F.conv2d(c, wc, stride=2)[0].permute(1, 2, 0)
+    _check_windows(gx, [(7, 244, 256, 496, 512), (0, 0, 12, 0, 16), (6, 100, 112, 200, 216)], ref_dgrad, gscale)
+
+
+def _rank_one_wgrad_ref(a, b, kind):
+    """corr[ky][kx] = sum_{n,y,x} a(input pixel feeding output pixel (y,x) through tap (ky,kx)) * b(output pixel), fp64 on
+    the GPU with shifted slices.  kind 'conv' : Conv2d k4 s2 p1, a at full resolution, b at half resolution;
+    kind 'convT': ConvTranspose2d k4 s2 p1, a at half resolution, b at full resolution."""
+    a, b = a.double(), b.double()
+    corr = torch.zeros(4, 4, dtype=torch.float64, device=a.device)
+    if kind == "conv":
+        ap = F.pad(a, (1, 1, 1, 1))                        # [N, H+2, W+2]; out (oy, ox) reads ap[2oy + ky, 2ox + kx]
+        OH, OW = b.shape[1], b.shape[2]
+        for ky in range(4):
+            for kx in range(4):
+                corr[ky, kx] = (ap[:, ky:ky + 2 * OH:2, kx:kx + 2 * OW:2] * b).sum()
+    else:
+        # out (oy, ox) = sum_iy in(iy, ix) w[ky][kx], oy = 2 iy - 1 + ky: b viewed from the input grid
+        bp = F.pad(b, (1, 1, 1, 1))                        # bp[2 iy + ky] = b[2 iy - 1 + ky]
+        IH_, IW_ = a.shape[1], a.shape[2]
+        for ky in range(4):
+            for kx in range(4):
+                corr[ky, kx] = (bp[:, ky:ky + 2 * IH_:2, kx:kx + 2 * IW_:2] * a).sum()
+    return corr
+
+
+@pytest.mark.parametrize("kind,Ci,Co", [("conv", 96, 192), ("convT", 384, 96)])
+def test_two_by_two_tap_weight_gradients_full_size(kind, Ci, Co):
+    """The direct row-split weight-gradient kernel on its 2x2-tap forms (Conv2d k4 s2 split into four kernel-parity
+    classes; the four parity classes of ConvTranspose2d k4 s2) at 8 x 512 x 1024: whole batch vs the sum of per-image
+    launches, and rank-one inputs vs their exact fp64 gradient."""
+    eng = _eng()
+    if kind == "conv":
+        xs, gs, wshape = (N, HH, WW, Ci), (N, HH // 2, WW // 2, Co), (Co, Ci, 4, 4)
+    else:
+        xs, gs, wshape = (N, HH // 2, WW // 2, Ci), (N, HH, WW, Co), (Ci, Co, 4, 4)
+    w = torch.zeros(*wshape, device=DEV, requires_grad=True)
+    plans = eng._launch_plan(kind, 4, 2, 1, w, "fwd")
+    x, g = _randn(*xs, seed=12), _randn(*gs, seed=13)
+    whole = eng._wgrad(plans, Act(x), g, Co, w).double()
+    parts = torch.zeros_like(whole)
+    for n in range(N):
+        parts += eng._wgrad(plans, Act(x[n:n + 1].contiguous()), g[n:n + 1].contiguous(), Co, w).double()
+    torch.cuda.synchronize()
+    assert float((whole - parts).abs().max()) < 2e-5 * float(parts.abs().max())
+    # rank-one inputs
+    a, b = _randn(*xs[:3], seed=14), _randn(*gs[:3], seed=15)
+    u, v = _randn(Ci, seed=16), _randn(Co, seed=17)
+    x.copy_(a[..., None] * u)
+    g.copy_(b[..., None] * v)
+    got = eng._wgrad(plans, Act(x), g, Co, w).double()
+    corr = _rank_one_wgrad_ref(a, b, kind)
+    if kind == "conv":
+        want = v.double()[:, None, None, None] * u.double()[None, :, None, None] * corr[None, None]
+    else:
+        want = u.double()[:, None, None, None] * v.double()[None, :, None, None] * corr[None, None]
+    torch.cuda.synchronize()
+    # sums of 1-4 M products of O(1) terms: fp32 accumulation noise ~ sqrt(P) * 1e-7 relative to sqrt(P)-sized sums
+    assert float((got - want).abs().max()) < 5e-5 * float(want.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (b) train-mode ConvBlock 96 -> 96 at 8 x 512 x 1024: BatchNorm statistics over 4.2 M pixels per channel
+# ---------------------------------------------------------------------------------------------------------------------
+def test_train_mode_convblock_batchnorm_full_size():
+    C = 96
+    P = N * HH * WW
+    eng = Engine(torch.device(DEV), record=True)
+    w = (_randn(C, C, 3, 3, seed=20) / (9 * C) ** 0.5).requires_grad_(True)
+    gamma = (1.0 + 0.2 * _randn(C, seed=21)).requires_grad_(True)
+    beta = (0.1 * _randn(C, seed=22)).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    x = Act(_randn(N, HH, WW, C, seed=23) + 0.3)
+    o = eng.conv(x, w, None, BNState(gamma, beta, rm, rv, nbt), kind="conv", k=3, stride=1, pad=1, relu=True, training=True)
+    torch.cuda.synchronize()
+    # raw convolution output from the same kernels, statistics in fp64 with torch on the GPU (test infrastructure)
+    e2 = _eng()
+    y = torch.empty(N, HH, WW, C, device=DEV)
+    e2._run_gather(e2._launch_plan("conv", 3, 1, 1, w, "fwd"), Act(x.t), y, C, w.detach())
+    mean = torch.zeros(C, dtype=torch.float64, device=DEV)
+    sq = torch.zeros(C, dtype=torch.float64, device=DEV)
+    for n in range(N):
+        yn = y[n].double()
+        mean += yn.sum((0, 1))
+        sq += (yn * yn).sum((0, 1))
+    mean /= P
+    var = sq / P - mean * mean
+    invstd = (var + 1e-5).rsqrt()
+    assert float((rm.double() - 0.1 * mean).abs().max()) < 1e-6
+    assert float((rv.double() - (0.9 + 0.1 * var * P / (P - 1))).abs().max()) < 1e-6
+    assert int(nbt) == 1
+    gout = _randn(N, HH, WW, C, seed=24)
+    dgamma = torch.zeros(C, dtype=torch.float64, device=DEV)
+    dbeta = torch.zeros(C, dtype=torch.float64, device=DEV)
+    worst = 0.0
+    for n in range(N):
+        xhat = (y[n].double() - mean) * invstd
+        pre = xhat * gamma.detach().double() + beta.detach().double()
+        worst = max(worst, float((o.t[n].double() - pre.clamp_min(0)).abs().max()))
+        gp = gout[n].double() * (o.t[n] > 0)      # the mask the kernels used (fp32 fma > 0): no kink flips in the reference
+        dgamma += (gp * xhat).sum((0, 1))
+        dbeta += gp.sum((0, 1))
+    assert worst < 2e-5, worst
+    o.grad = gout
+    eng.backward()
+    torch.cuda.synchronize()
+    got_g, got_b = eng.param_grads[id(gamma)].double(), eng.param_grads[id(beta)].double()
+    assert float((got_g - dgamma).abs().max()) < 2e-5 * float(dgamma.abs().max()) + 1e-2   # sums of 4.2 M terms
+    assert float((got_b - dbeta).abs().max()) < 2e-5 * float(dbeta.abs().max()) + 1e-2
+    # input gradient on crops: g_y = gamma*invstd*(g' - dbeta/P - xhat*dgamma/P) in fp64, then the 3x3 data gradient
+    wc = w.detach().cpu().double()
+    k = (gamma.detach().double() * invstd)
+
+    def ref(n, y0, y1, x0, x1):
+        ys, ye, xs, xe = max(y0 - 2, 0), min(y1 + 2, HH), max(x0 - 2, 0), min(x1 + 2, WW)
+        yc = y[n, ys:ye, xs:xe].double()
+        xhat = (yc - mean) * invstd
+        gp = gout[n, ys:ye, xs:xe].double() * (o.t[n, ys:ye, xs:xe] > 0)
+        gy = k * (gp - dbeta / P - xhat * dgamma / P)
+        r = F.conv_transpose2d(gy.permute(2, 0, 1)[None].cpu(), wc, padding=1)[0].permute(1, 2, 0)
+        return r[y0 - ys:y1 - ys, x0 - xs:x1 - xs]
+    gx = x.grad
+    _check_windows(gx, [(7, 480, 512, 976, 1024), (0, 0, 32, 0, 48), (3, 200, 232, 600, 648)], ref, float(gx.abs().max()),
+                   tol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (c) AttentionBlock, 96 channels, 8 x 512 x 1024 (HW = 524 288 per image)
+# ---------------------------------------------------------------------------------------------------------------------
+def _cbam_ref64(x_nhwc, w1, w2, wsp):
+    """base_model.py:43-78 in fp64 on NHWC input [n, H, W, C] (torch on the GPU, test infrastructure)."""
+    x = x_nhwc.double()
+    avg, mx = x.mean((1, 2)), x.amax((1, 2))
+    W1, W2 = w1.double().flatten(1), w2.double().flatten(1)
+    fc = lambda v: torch.relu(v @ W1.t()) @ W2.t()
+    ca = torch.sigmoid(fc(avg) + fc(mx))
+    xc = x * ca[:, None, None, :]
+    s = torch.stack([xc.mean(3), xc.amax(3)], 1)                    # [n, 2, H, W]
+    sa = torch.sigmoid(F.conv2d(s, wsp.double(), padding=3))          # [n, 1, H, W]
+    return xc * sa[:, 0, :, :, None]
+
+
+def test_attention_block_full_size_forward_backward():
+    C, Ch = 96, 6
+    eng = Engine(torch.device(DEV), record=True)
+    w1 = (_randn(Ch, C, 1, 1, seed=30) / C ** 0.5).requires_grad_(True)
+    w2 = (_randn(C, Ch, 1, 1, seed=31) / Ch ** 0.5).requires_grad_(True)
+    wsp = (_randn(1, 2, 7, 7, seed=32) / 98 ** 0.5).requires_grad_(True)
+    xt = _randn(N, HH, WW, C, seed=33)
+    x = Act(xt)
+    o = eng.attention(x, w1, w2, wsp)
+    gout = _randn(N, HH, WW, C, seed=34)
+    o.grad = gout
+    out = o.t
+    eng.backward()
+    torch.cuda.synchronize()
+    gx = x.grad
+    # per-image independence: image 7 alone gives the same output
+    e1 = _eng()
+    alone = e1.attention(Act(xt[7:8].contiguous()), w1, w2, wsp).t
+    assert float((alone[0] - out[7]).abs().max()) < 1e-6
+    # fp64 definition, forward and backward, image by image for the first and the last image (4 GB of fp64 each)
+    dw1 = torch.zeros_like(w1, dtype=torch.float64)
+    dw2 = torch.zeros_like(w2, dtype=torch.float64)
+    dws = torch.zeros_like(wsp, dtype=torch.float64)
+    for n in range(N):
+        xr = xt[n:n + 1].double().requires_grad_(True)
+        a1, a2, a3 = (t_.detach().double().requires_grad_(True) for t_ in (w1, w2, wsp))
+        ref = _cbam_ref64(xr, a1, a2, a3)
+        assert float((out[n:n + 1].double() - ref.detach()).abs().max()) < 2e-5 * float(ref.detach().abs().max())
+        (ref * gout[n:n + 1].double()).sum().backward()
+        dw1 += a1.grad
+        dw2 += a2.grad
+        dws += a3.grad
+        if n in (0, 7):
+            # the channel arg-max of the spatial branch is taken on fp32 values here and on fp64 values in the reference:
+            # with 524 288 pixels a few top-2 gaps sit below fp32 resolution and route their (small) gradient to the other
+            # channel -- allow a handful of such pixels, bound everything else tightly
+            err = (gx[n:n + 1].double() - xr.grad).abs()
+            gs = float(xr.grad.abs().max())
+            assert int((err > 5e-5 * gs).sum()) <= 64, int((err > 5e-5 * gs).sum())
+            assert float(err.max()) < 0.5 * gs
+        del xr, ref
+    for got, want in ((eng.param_grads[id(w1)], dw1), (eng.param_grads[id(w2)], dw2), (eng.param_grads[id(wsp)], dws)):
+        assert float((got.double() - want).abs().max()) < 1e-4 * float(want.abs().max()) + 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (d) whole models at the config sizes
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config3_medium_train_step_bs16_properties():
+    """BASELINE.json config 3: CORUN-Medium train-mode forward + DehazingLoss + backward + Adam at bs 16, 512 x 1024.
+    Properties: finite loss, equal across two runs from the same state (deterministic kernels, fixed reduction order),
+    every parameter receives a finite gradient and moves."""
+    from adam_dehaze_amd.loss import DehazingLoss
+    from adam_dehaze_amd.optim import Adam
+    import warnings
+    hazy, clear, _ = R.synthetic_batch(16, HH, WW, seed=5)
+    hazy, clear = hazy.to(DEV), clear.to(DEV)
+    losses = []
+    for run in range(2):
+        torch.manual_seed(7)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = A.MediumIntensityDehazeModel().to(DEV).train()
+            crit = DehazingLoss().to(DEV)
+        opt = Adam(m.parameters(), lr=1e-4, weight_decay=1e-4)
+        before = {k: v.detach().clone() for k, v in m.named_parameters()}
+        out = m(hazy)
+        assert out.shape == hazy.shape and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+        loss, comps = crit(out, clear)
+        loss.backward()
+        for k, p in m.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        opt.step()
+        torch.cuda.synchronize()
+        moved = sum(int(not torch.equal(before[k], p.detach())) for k, p in m.named_parameters())
+        assert moved >= len(before) - 2          # ConvTranspose biases feeding train-mode BN have zero gradient
+        losses.append((float(loss), float(comps["l1"]), float(comps["content"]), float(comps["perceptual"])))
+        del m, crit, opt, out, loss
+        torch.cuda.empty_cache()
+    assert all(v == v and abs(v) < 1e4 for v in losses[0])
+    assert losses[0] == losses[1], losses
+
+
+def test_config5_complex_eval_1024x2048_properties():
+    """BASELINE.json config 5 frames: CORUN-Complex eval forward on 4 x 3 x 1024 x 2048: range, determinism, batch
+    independence, and agreement of a 512 x 1024 top-left window's interior with the oracle's receptive-field-limited
+    value is NOT available (global attention pools) -- so independence and determinism are the size-independent checks."""
+    torch.manual_seed(4)
+    m = A.HighIntensityDehazeModel().to(DEV).train()
+    hazy, _, _ = R.synthetic_batch(4, 1024, 2048, seed=9)
+    x = hazy.to(DEV)
+    with torch.no_grad():
+        m(x[:1, :, :256, :512].contiguous())      # one train-mode pass: BN running statistics are not the identity
+    m.eval()
+    with torch.no_grad():
+        both = m(x)
+        again = m(x)
+        one = m(x[3:4].contiguous())
+    assert both.shape == x.shape and float(both.min()) >= 0.0 and float(both.max()) <= 1.0
+    assert torch.equal(both, again)
+    assert float((both[3:4] - one).abs().max()) < 1e-6
+    assert float((both - x).abs().max()) > 1e-3    # the network does something

@@ -115,18 +115,38 @@ BRANCHES = [
 ]
 
 
+ORACLE_FWD = {"light_b8": R.lightweight_forward, "lowint_b8": R.low_intensity_forward, "medium_b8": R.medium_forward,
+              "medium_b8_odd": R.medium_forward, "corun_b8": R.corun_forward, "high_b16": R.high_forward,
+              "high_b16_odd": R.high_forward, "dual_b16": R.dual_branch_forward}
+
+
+def _fp64_fixture_grads(name, rec):
+    """Parameter gradients of the fixture's objective (train-mode forward, L1 against rec['target']) from the oracle run
+    in float64 on the fixture's own state_dict and input: the anchor both fp32 implementations are measured against."""
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sub_sd(rec).items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    out = ORACLE_FWD[name](t(rec["x"]).double(), sd, training=True)
+    F.l1_loss(out, t(rec["target"]).double()).backward()
+    return {k: v.grad for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+
+
 @pytest.mark.parametrize("wino", [False, True, 23], ids=["direct", "winograd", "winograd-f23"])
 @pytest.mark.parametrize("name,ctor", BRANCHES)
 def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
-    """Whole branches against the fixtures generated from the reference (tools/gen_golden.py).
+    """Whole branches against the fixtures generated from the reference (tools/gen_golden.py): eval output, train
+    output, L1 loss, every parameter gradient, BN buffers.
 
-    Parameter gradients are gated strictly (5e-3 of the tensor's scale, element-wise) on the direct convolution
-    path, whose accumulation order follows the reference closely.  The Winograd path computes the same
-    convolutions with different rounding (per-layer agreement with the direct kernels is checked to ~1e-6 in
-    test_conv_forward_dgrad_wgrad_vs_oracle and test_winograd_matches_direct_path); over a dozen BatchNorm layers
-    that becomes ~1e-5 on activations, enough to flip a ReLU whose input sits within 1e-5 of zero.  In these
-    deliberately tiny fixtures (a 7x11 bottleneck) one flipped element moves a weight gradient by a few per cent
-    (measured: tools/wino_debug3.py), so that path is gated on the relative L2 error plus a looser element bound."""
+    Gradient gate (every path, every fixture): the fixture holds the reference's own fp32 CPU gradients; the oracle run
+    in float64 on the same state gives the exact ones.  The HIP gradient of every tensor must be as close to float64 as
+    the reference's fp32 gradient is: err_gpu <= 3 * err_ref + 2e-3 (max-abs over the tensor's scale).  These networks
+    contain ReLU / arg-max kinks, and in these deliberately tiny fixtures (a 7x11 bottleneck) one activation within
+    rounding distance of its kink moves a whole tensor by a few per cent under ANY change of summation order; so at
+    most four tensors (two layers' weight + BN bias) may miss the strict bound, and all must meet 10 * err_ref + 5e-3
+    -- the criterion of test_complex_fullwidth_vs_oracle_seeded.  On the direct path, whose accumulation order follows
+    the reference closely, the tight element-wise bound against the fixture (5e-3) is kept as well.  The per-tensor table
+    of the last run is written to gpurun_out/grad_gate_<path>.txt (committed under profiles/)."""
     import adam_dehaze_amd.engine as E
     monkeypatch.setattr(E, "USE_WINOGRAD", bool(wino))
     monkeypatch.setattr(E, "USE_WINO43", wino != 23)
@@ -147,25 +167,35 @@ def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
     loss = l1_loss(out, t(rec["target"]).to(DEV))
     assert abs(float(loss) - float(rec["l1"])) < 1e-5
     loss.backward()
-    bad = []
+    g64 = _fp64_fixture_grads(name, rec)
+    path = {False: "direct", True: "f43", 23: "f23"}[wino]
+    bad, worse, tight, lines = [], [], [], []
     for pname, p in m.named_parameters():
-        ref = t(rec["gp_train." + pname])
-        g = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)
-        scale = max(float(ref.abs().max()), 1e-8)
-        err = float((g - ref).abs().max())
-        rel2 = float((g - ref).norm() / max(float(ref.norm()), 1e-8))
-        if os.environ.get("ADH_TEST_VERBOSE"):
-            print(f"{name:16s} {pname:44s} max-abs/scale {err / scale:.2e}  rel-L2 {rel2:.2e}  scale {scale:.2e}")
-        if not wino or scale < 1e-6:   # (a bias feeding train-mode BatchNorm has a zero true gradient)
-            ok = err < 5e-3 * scale + 2e-7
-        elif wino == 23:
-            ok = rel2 < 3e-2 and err < 8e-2 * scale + 2e-7
-        else:   # F(4x4,3x3) rounds ~8x coarser than F(2x2,3x3): more kink flips in these tiny fixtures; its gradients
-            # are judged against the fp64 oracle at full width in test_complex_fullwidth_vs_oracle_seeded
-            ok = rel2 < 8e-2 and err < 2e-1 * scale + 2e-7
-        if not ok:
-            bad.append((pname, err, scale, rel2))
-    assert not bad, bad[:8]
+        ref32 = t(rec["gp_train." + pname]).double()
+        ref64 = g64[pname]
+        g = (p.grad.cpu() if p.grad is not None else torch.zeros_like(ref32)).double()
+        scale = max(float(ref64.abs().max()), 1e-8)
+        err_ref = float((ref32 - ref64).abs().max()) / scale
+        err_gpu = float((g - ref64).abs().max()) / scale
+        lines.append(f"{name:14s} {path:6s} {pname:44s} scale {scale:.2e}  err_ref {err_ref:.2e}  err_gpu {err_gpu:.2e}")
+        if scale < 1e-6:      # a bias feeding train-mode BatchNorm: the true gradient is exactly 0, both sides hold noise
+            assert float(g.abs().max()) < 1e-6, pname
+            continue
+        if not err_gpu <= 3.0 * err_ref + 2e-3:
+            bad.append((pname, err_gpu, err_ref))
+        if not err_gpu <= 10.0 * err_ref + 5e-3:
+            worse.append((pname, err_gpu, err_ref))
+        if not wino and not float((g - ref32).abs().max()) < 5e-3 * max(float(ref32.abs().max()), 1e-8) + 2e-7:
+            tight.append((pname, err_gpu, err_ref))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", f"grad_gate_{path}.txt"), "a") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    assert not worse, worse[:8]
+    assert len(bad) <= 4, bad[:8]
+    assert not tight, tight[:8]
     after = sub_sd(rec, "sd_after_train.")
     for k, v in m.state_dict().items():
         if "running" in k or "num_batches" in k:

@@ -38,8 +38,8 @@ def test_joint_step_composition_vs_oracle():
     clf, models, router, crit = system["classifier"], system["models"], system["router"], system["criterion"]
     sd_clf = {k: v.detach().cpu().clone() for k, v in clf.state_dict().items()}
     sds = {n: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for n, m in models.items()}
-    batch = next(T.synthetic_loader(4, 32, 1, seed=3))
-    hazy, clear, labels = batch["hazy"], batch["clear"], batch["intensity"]
+    batch = next(T.synthetic_loader(4, 32, 1, seed=3, device=DEV))
+    hazy, clear, labels = batch["hazy"].cpu(), batch["clear"].cpu(), batch["intensity"].cpu()
 
     # oracle
     for sd in list(sds.values()) + [sd_clf]:
@@ -88,18 +88,133 @@ def test_joint_training_runs_and_uses_duplicate_param_adam():
     system["classifier"].train()
     system["router"].train()
     losses = []
-    for batch in T.synthetic_loader(4, 32, 3, seed=5):
+    for batch in T.synthetic_loader(4, 32, 3, seed=5, device=DEV):
         losses.append(float(T.joint_train_step(system, batch)["loss"]))
     assert all(l == l and l < 1e3 for l in losses)
     assert not torch.equal(before, high_p.detach())
     assert opt.state[id(high_p)]["step"] == 6 and opt.state[id(clf_p)]["step"] == 3
 
 
-def test_branch_training_step_reduces_l1():
+def test_branch_training_step_vs_oracle(monkeypatch):
+    """T2 (train_dehazing.py:71-106) on a mixed-label batch against the oracle: keep the images of the branch's level ->
+    Medium train-mode forward -> L1 -> backward -> one Adam(lr 1e-4, wd 1e-4) step.  Checked: the filtered loss, every
+    parameter gradient, the optimiser applied to those gradients (exactly), the BN buffers, and the parameters after
+    the step against the all-oracle step wherever the first Adam step is sign-stable (it moves every element by
+    lr * g / (|g| + 1e-8): elements whose gradient is ~1e-8 amplify rounding into the update)."""
+    import adam_dehaze_amd.engine as E
+    from adam_dehaze_amd.loss import DehazingLoss
+    from adam_dehaze_amd.optim import Adam
+    monkeypatch.setattr(E, "USE_WINOGRAD", False)     # the direct kernels follow the reference's summation order closely
+    torch.manual_seed(11)
+    model = A.MediumIntensityDehazeModel(base_channels=8).to(DEV).train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    hazy, clear, _ = R.synthetic_batch(6, 32, 48, seed=21)
+    labels = torch.tensor([1, 0, 1, 2, 1, 1])
+    crit = DehazingLoss(content=False, perceptual=False).to(DEV)
+    opt = Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    st = T.dehazing_train_step(model, crit, opt, {"hazy": hazy, "clear": clear, "intensity": labels}, 1, DEV)
+    torch.cuda.synchronize()
+    # oracle: the same step on the CPU
+    keep = labels == 1
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    out = R.medium_forward(hazy[keep], sd, training=True)
+    loss_r = F.l1_loss(out, clear[keep])
+    loss_r.backward()
+    assert abs(float(st["loss"]) - float(loss_r)) < 1e-5 and abs(float(st["l1"]) - float(loss_r)) < 1e-5
+    names = dict(model.named_parameters())
+    stable = total = 0
+    for k, p in names.items():
+        g_ref = sd[k].grad
+        g = p.grad.cpu()
+        scale = max(float(g_ref.abs().max()), 1e-8)
+        noise = k.startswith("decoder") and k.endswith(".0.bias")       # ConvTranspose bias feeding train-mode BN: true grad 0
+        if not noise:
+            assert float((g - g_ref).abs().max()) < 5e-3 * scale + 2e-7, k
+        # the optimiser on the GPU's own gradient: exact
+        p_exp, m, v = sd0[k].clone(), torch.zeros_like(g), torch.zeros_like(g)
+        R.adam_step(p_exp, g, m, v, step=0, lr=1e-4, weight_decay=1e-4)
+        assert max_abs(p.detach(), p_exp) < 2e-7, k
+        assert max_abs(opt.state[id(p)]["m"], m) < 1e-7 * max(1.0, float(m.abs().max())), k
+        # the whole step against the all-oracle step where the update is sign-stable
+        p_ref, m, v = sd0[k].clone(), torch.zeros_like(g), torch.zeros_like(g)
+        R.adam_step(p_ref, g_ref.clone(), m, v, step=0, lr=1e-4, weight_decay=1e-4)
+        sel = (g_ref + 1e-4 * sd0[k]).abs() > 1e-5 * scale + 1e-6
+        if not noise and bool(sel.any()):
+            assert float((p.detach().cpu() - p_ref)[sel].abs().max()) < 1e-6, k
+        stable += int(sel.sum())
+        total += sel.numel()
+    assert stable > 0.9 * total
+    for k, v in model.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert max_abs(v, sd[k]) < 1e-5, k
+    assert opt.state[id(next(model.parameters()))]["step"] == 1
+    # a batch without any image of the level is skipped, like train_dehazing.py:75-76
+    assert T.dehazing_train_step(model, crit, opt, {"hazy": hazy, "clear": clear,
+                                                    "intensity": torch.zeros(6, dtype=torch.long)}, 1, DEV) is None
+
+
+def test_dehazing_driver_validation_checkpoints_and_resume(tmp_path):
+    """train_dehazing_model: epochs of train + validation (device PSNR / SSIM), the reference's checkpoint key sets
+    (train_dehazing.py:196-203,208-215), and --resume continuing from the latest checkpoint with the optimiser state."""
     cfg = _cfg()
+    cfg["dehazing"]["checkpoint_dir"] = str(tmp_path / "dehazing")
     torch.manual_seed(3)
-    model, losses = T.train_dehazing_model(cfg, "medium", steps=6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, losses = T.train_dehazing_model(cfg, "medium", steps=3, epochs=5, val_steps=2)
     assert len(losses) >= 3 and all(l == l for l in losses)
+    ck_dir = tmp_path / "dehazing" / "medium"
+    best = torch.load(ck_dir / "best_model.pth", map_location="cpu")
+    per5 = torch.load(ck_dir / "checkpoint_epoch_5.pth", map_location="cpu")
+    want = {"epoch", "model_state_dict", "optimizer_state_dict", "val_psnr", "val_ssim", "val_loss"}
+    assert want <= set(best) and want <= set(per5) and per5["epoch"] == 4
+    assert 0.0 < best["val_psnr"] < 100.0 and -1.0 <= best["val_ssim"] <= 1.0
+    assert set(per5["model_state_dict"]) == set(model.state_dict())
+    # the optimiser state is torch-loadable
+    tm = [torch.nn.Parameter(v.clone()) for v in model.parameters()]
+    topt = torch.optim.Adam(tm, lr=1.0)
+    topt.load_state_dict(per5["optimizer_state_dict"])
+    nsteps = {int(s["step"]) for s in topt.state_dict()["state"].values()}
+    assert len(nsteps) == 1 and nsteps.pop() == len(losses)
+    # resume: continues at epoch 6 from checkpoint_epoch_5 (one more epoch), parameters start where they were saved
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model2, losses2 = T.train_dehazing_model(cfg, "medium", steps=3, epochs=6, val_steps=2, resume=True)
+    assert 1 <= len(losses2) <= 3
+    with pytest.raises(FileNotFoundError):
+        T.train_dehazing_model(cfg, "low", steps=1, epochs=1, resume=True)
+
+
+def test_joint_driver_validation_and_checkpoint_keys(tmp_path):
+    """train_joint_model: train + validate_joint (train_joint.py:173-236 on device) + checkpoint dicts with exactly the
+    reference's keys (train_joint.py:272-283) + resume."""
+    cfg = _cfg()
+    cfg["joint_training"]["checkpoint_dir"] = str(tmp_path / "joint")
+    cfg["joint_training"]["epochs"] = 1
+    torch.manual_seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        system, hist = T.train_joint_model(cfg, steps_per_epoch=2, val_steps=1)
+    assert len(hist) == 1 and hist[0]["val_samples"] == 4
+    for k in ("train_loss", "val_loss", "val_dehaze_loss", "val_class_loss", "val_psnr", "val_ssim"):
+        assert hist[0][k] == hist[0][k]
+    ck = torch.load(tmp_path / "joint" / "best_model.pth", map_location="cpu")
+    ref_keys = {"epoch", "router_state_dict", "low_model_state_dict", "medium_model_state_dict", "high_model_state_dict",
+                "classifier_state_dict", "optimizer_state_dict", "val_psnr", "val_ssim", "val_loss"}
+    assert ref_keys <= set(ck) and set(ck) - ref_keys == {"scheduler_state_dict"}
+    # duplicated parameters are packed once in the optimiser state, like torch does
+    n_unique = len({id(p) for p in system["router"].parameters()})
+    assert len(ck["optimizer_state_dict"]["state"]) <= n_unique
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cfg["joint_training"]["epochs"] = 2
+        system2, hist2 = T.train_joint_model(cfg, steps_per_epoch=1, val_steps=1, resume=True)
+    assert [h["epoch"] for h in hist2] == [1]
+    high_p = next(system2["models"]["high"].parameters())
+    assert system2["optimizer"].state[id(high_p)]["step"] == 2 * (2 + 1)      # 2 steps restored + 1, listed twice
 
 
 def test_complex_eval_forward_large_frame_properties():
