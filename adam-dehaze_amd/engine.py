@@ -63,6 +63,9 @@ def _layout_key(L: WLayout) -> tuple:
 # the moment the gradient is final (all of the parameter's uses in this engine have been processed), so a bucket's
 # all-reduce can start while the rest of the backward pass is still running.
 # ---------------------------------------------------------------------------------------------------------------------
+# Test hook (tests/_util.py: kink_matched): when a dict, every fused conv(+BN)+ReLU op stores its post-activation output
+# under id(weight), so a test can replay the ReLU masks this implementation actually used in the float64 oracle.
+RELU_CAPTURE: Optional[Dict[int, torch.Tensor]] = None
 GRAD_SINK: Optional[Callable[[torch.Tensor], Optional[torch.Tensor]]] = None
 GRAD_READY: Optional[Callable[[torch.Tensor, torch.Tensor], None]] = None
 
@@ -593,7 +596,8 @@ class Engine:
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
             H.call("adh_bn_apply", y.data_ptr(), y.stride(2), scale.data_ptr(), shift.data_ptr(), H.ptr(res_t),
-                   res_t.stride(2) if res_t is not None else 0, act_code, out.data_ptr(), out.stride(2), P, Cout)
+                   res_t.stride(2) if res_t is not None else 0, act_code, out.data_ptr(), out.stride(2), P, Cout,
+                   work=4.0 * P * Cout * (3 if res_t is not None else 2))     # bytes: read y (+ residual), write out
             saved = ("train", y, mean, invstd, ss)
         elif bn is not None:
             scale, shift = self._f(Cout), self._f(Cout)
@@ -606,6 +610,8 @@ class Engine:
             saved = ("plain",)
 
         o = Act(out, Cout)
+        if RELU_CAPTURE is not None and relu:
+            RELU_CAPTURE[id(w)] = out
         if self.record:
             # the parameters _conv_backward will produce a gradient for (must mirror its add_param_grad calls)
             self.use_param(w if (w.requires_grad or self.alias.get(id(w)) is not None) else None, b,
@@ -638,7 +644,8 @@ class Engine:
             nblk = H.value("adh_bn_bwd_num_blocks", P, C4)
             partial = self._f(nblk, 2, C4)
             H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
-                   y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4, mask_ss)
+                   y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4, mask_ss,
+                   work=4.0 * P * Cout * (2 if (mask_ss is not None or not relu) else 3))   # bytes: g, y (+ out for the mask)
             if C4 == Cout:
                 dgamma, dbeta = self.grad_buffer(bn.weight), self.grad_buffer(bn.bias)
             else:
@@ -648,7 +655,8 @@ class Engine:
                    invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
             H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
                    y.stride(2), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), 1, g_y.data_ptr(), g_y.stride(2),
-                   H.ptr(g_res), g_res.stride(2) if g_res is not None else 0, P, C4, mask_ss)
+                   H.ptr(g_res), g_res.stride(2) if g_res is not None else 0, P, C4, mask_ss,
+                   work=4.0 * P * Cout * ((2 if (mask_ss is not None or not relu) else 3) + 1 + (1 if g_res is not None else 0)))
             self.add_param_grad(bn.weight, dgamma[:Cout])
             self.add_param_grad(bn.bias, dbeta[:Cout])
             if b is not None:   # a bias feeding train-mode BN has an exactly zero gradient
@@ -696,8 +704,9 @@ class Engine:
         partial_idx = torch.empty((N, nblk, Cc), device=self.device, dtype=torch.int32)
         pooled = self._f(N, 2, Cc)
         amax_idx = torch.empty((N, Cc), device=self.device, dtype=torch.int32)
+        xbytes = 4.0 * N * HW * Cc
         H.call("adh_cbam_pool", x.t.data_ptr(), x.cs, N, HW, Cc, partial.data_ptr(), partial_idx.data_ptr(), nblk,
-               pooled.data_ptr(), amax_idx.data_ptr())
+               pooled.data_ptr(), amax_idx.data_ptr(), work=xbytes)
         ca = self._f(N, Cc)
         hidden = self._f(N, 2, Ch)
         H.call("adh_cbam_mlp", pooled.data_ptr(), w1.data_ptr(), w2.data_ptr(), N, Cc, Ch, ca.data_ptr(),
@@ -705,13 +714,13 @@ class Engine:
         smap = self._f(N, HW, 2)
         cidx = torch.empty((N, HW), device=self.device, dtype=torch.int32)
         H.call("adh_cbam_spatial_stats", x.t.data_ptr(), x.cs, ca.data_ptr(), N, HW, Cc, smap.data_ptr(),
-               cidx.data_ptr())
+               cidx.data_ptr(), work=xbytes)
         sa = self._f(N, HW)
         if out is None:
             out = self._f(N, Hh, Ww, Cc)
         _check_dense_pixels(out)
         H.call("adh_cbam_apply", x.t.data_ptr(), x.cs, ca.data_ptr(), smap.data_ptr(), wsp.data_ptr(), N, Hh, Ww, Cc,
-               sa.data_ptr(), out.data_ptr(), out.stride(2))
+               sa.data_ptr(), out.data_ptr(), out.stride(2), work=2 * xbytes)
         o = Act(out, Cc)
         if self.record:
             self.use_param(wsp, w1, w2)
@@ -723,7 +732,7 @@ class Engine:
                     return
                 gsa_pre = self._f(N, HW)
                 H.call("adh_cbam_bwd_a", g.data_ptr(), g.stride(2), x.t.data_ptr(), x.cs, ca.data_ptr(), sa.data_ptr(),
-                       N, HW, Cc, gsa_pre.data_ptr())
+                       N, HW, Cc, gsa_pre.data_ptr(), work=2 * xbytes)
                 nb = H.value("adh_cbam_bwd_b_num_blocks", N, Hh, Ww)
                 gsmap = self._f(N, HW, 2)
                 dwsp_partial = self._f(nb, 98)
@@ -732,7 +741,7 @@ class Engine:
                        gsmap.data_ptr(), dwsp_partial.data_ptr(), nb, dwsp.data_ptr(), 0)
                 gca_partial = self._f(N, nblk, Cc)
                 H.call("adh_cbam_bwd_c", g.data_ptr(), g.stride(2), x.t.data_ptr(), x.cs, sa.data_ptr(),
-                       gsmap.data_ptr(), cidx.data_ptr(), N, HW, Cc, gca_partial.data_ptr(), nblk)
+                       gsmap.data_ptr(), cidx.data_ptr(), N, HW, Cc, gca_partial.data_ptr(), nblk, work=2 * xbytes)
                 gpool = self._f(N, 2, Cc)
                 dw1, dw2 = self.grad_buffer(w1), self.grad_buffer(w2)
                 H.call("adh_cbam_bwd_d", gca_partial.data_ptr(), nblk, ca.data_ptr(), pooled.data_ptr(),
@@ -745,7 +754,7 @@ class Engine:
                     gx = self._f(N, Hh, Ww, Cc)
                     H.call("adh_cbam_bwd_e", g.data_ptr(), g.stride(2), x.t.data_ptr(), x.cs, ca.data_ptr(),
                            sa.data_ptr(), gsmap.data_ptr(), cidx.data_ptr(), gpool.data_ptr(), amax_idx.data_ptr(), N,
-                           HW, Cc, gx.data_ptr(), gx.stride(2))
+                           HW, Cc, gx.data_ptr(), gx.stride(2), work=3 * xbytes)
                     self.accum(x, gx)
             self.tape.append(bwd)
         return o

@@ -38,12 +38,19 @@ def main():
     x, y = hazy[2 * rank:2 * rank + 2].to(dev), clear[2 * rank:2 * rank + 2].to(dev)
     rec = {"sd0": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "nbuckets": [], "early": [],
            "order": []}
+    import adam_dehaze_amd.engine as E
     for step in range(3):
         opt.zero_grad()
         sync.begin_step()
+        if step == 0:
+            E.RELU_CAPTURE = {}
         out = model(x)
         loss = l1_loss(out, y)
         loss.backward()
+        if step == 0:   # the ReLU masks this rank's kernels used, for the kink-matched oracle of the parent test
+            rec["masks"] = {k: (E.RELU_CAPTURE[id(p)] > 0).permute(0, 3, 1, 2).cpu() for k, p in model.named_parameters()
+                            if id(p) in E.RELU_CAPTURE}
+            E.RELU_CAPTURE = None
         rec["early"].append(sync._next_bucket)          # buckets already in flight when backward returned
         rec["nbuckets"].append(len(sync.buckets))
         rec["order"].append(list(sync.order))

@@ -42,3 +42,55 @@ def rel_err(a, b):
     if a.numel() == 0:
         return 0.0
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+
+
+class kink_matched:
+    """Context manager around a HIP forward (+ backward): records the post-ReLU output of every fused conv+ReLU op of
+    `model` (engine.RELU_CAPTURE) so that `.masks()` can hand the ReLU masks the kernels actually used to the oracle
+    (oracle.ref_cpu.KINK_MASKS).  With matched masks both sides differentiate the same piece of the piecewise-smooth
+    network, and the gradient comparison no longer has to tolerate flipped kinks."""
+
+    def __init__(self, model):
+        self.model = model
+        self.cap = {}
+
+    def __enter__(self):
+        import adam_dehaze_amd.engine as E
+        self._E = E
+        self._old = E.RELU_CAPTURE
+        E.RELU_CAPTURE = self.cap
+        return self
+
+    def __exit__(self, *exc):
+        self._E.RELU_CAPTURE = self._old
+        return False
+
+    def masks(self):
+        """{conv weight parameter name: bool mask [N, >=C, H, W] on the CPU} (channel padding of the NHWC buffers kept;
+        oracle_with_masks crops it)."""
+        out = {}
+        for name, p in self.model.named_parameters():
+            o = self.cap.get(id(p))
+            if o is not None:
+                out[name] = (o > 0).permute(0, 3, 1, 2).cpu()
+        return out
+
+
+def oracle_with_masks(fn, masks):
+    """Run `fn()` (an oracle forward + backward) with the ReLUs that follow the listed convolutions forced to `masks`."""
+    from oracle import ref_cpu as R
+    old = R.KINK_MASKS
+    R.KINK_MASKS = {k: m for k, m in masks.items()}
+    old_relu = R._relu
+
+    def _relu(y, key):
+        m = masks.get(key)
+        if m is None:
+            return old_relu(y, key)
+        return y * m[:, :y.shape[1]].to(y.dtype)
+    R._relu = _relu
+    try:
+        return fn()
+    finally:
+        R._relu = old_relu
+        R.KINK_MASKS = old

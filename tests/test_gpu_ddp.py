@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ref_cpu as R
+from tests._util import oracle_with_masks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,9 +48,13 @@ def test_two_rank_training_step_matches_shardwise_oracle(tmp_path):
         for k, v in sd.items():
             if v.is_floating_point() and "running" not in k:
                 v.requires_grad_(True)
-        out = R.high_forward(hazy[2 * r:2 * r + 2], sd, training=True)
-        loss = F.l1_loss(out, clear[2 * r:2 * r + 2])
-        loss.backward()
+
+        def run():
+            out = R.high_forward(hazy[2 * r:2 * r + 2], sd, training=True)
+            loss = F.l1_loss(out, clear[2 * r:2 * r + 2])
+            loss.backward()
+            return loss
+        loss = oracle_with_masks(run, recs[r]["masks"])      # the ReLU masks that rank's kernels used (tests/_util.py)
         assert abs(float(loss) - recs[r]["loss"]) < 1e-5
         shard_grads.append({k: sd[k].grad for k in recs[0]["grads"]})
         shard_bn.append({k: v.detach() for k, v in sd.items() if "running" in k})

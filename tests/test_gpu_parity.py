@@ -12,7 +12,7 @@ import adam_dehaze_amd as A
 from adam_dehaze_amd.engine import Act, Engine
 from adam_dehaze_amd.layers import AttentionBlock, ConvBlock, ResidualBlock
 from oracle import ref_cpu as R
-from tests._util import load_golden, sub_sd, t, max_abs, rel_err
+from tests._util import kink_matched, load_golden, oracle_with_masks, sub_sd, t, max_abs, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -120,16 +120,20 @@ ORACLE_FWD = {"light_b8": R.lightweight_forward, "lowint_b8": R.low_intensity_fo
               "high_b16_odd": R.high_forward, "dual_b16": R.dual_branch_forward}
 
 
-def _fp64_fixture_grads(name, rec):
+def _fp64_fixture_grads(name, rec, masks=None):
     """Parameter gradients of the fixture's objective (train-mode forward, L1 against rec['target']) from the oracle run
-    in float64 on the fixture's own state_dict and input: the anchor both fp32 implementations are measured against."""
-    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sub_sd(rec).items()}
-    for k, v in sd.items():
-        if v.is_floating_point() and "running" not in k:
-            v.requires_grad_(True)
-    out = ORACLE_FWD[name](t(rec["x"]).double(), sd, training=True)
-    F.l1_loss(out, t(rec["target"]).double()).backward()
-    return {k: v.grad for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    in float64 on the fixture's own state_dict and input: the anchor both fp32 implementations are measured against.
+    `masks`: ReLU masks to replay (tests/_util.py kink_matched) -- the exact gradient of the piece of the network the
+    HIP path actually differentiated."""
+    def run():
+        sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sub_sd(rec).items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+        out = ORACLE_FWD[name](t(rec["x"]).double(), sd, training=True)
+        F.l1_loss(out, t(rec["target"]).double()).backward()
+        return {k: v.grad for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    return oracle_with_masks(run, masks) if masks else run()
 
 
 @pytest.mark.parametrize("wino", [False, True, 23], ids=["direct", "winograd", "winograd-f23"])
@@ -138,15 +142,16 @@ def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
     """Whole branches against the fixtures generated from the reference (tools/gen_golden.py): eval output, train
     output, L1 loss, every parameter gradient, BN buffers.
 
-    Gradient gate (every path, every fixture): the fixture holds the reference's own fp32 CPU gradients; the oracle run
-    in float64 on the same state gives the exact ones.  The HIP gradient of every tensor must be as close to float64 as
-    the reference's fp32 gradient is: err_gpu <= 3 * err_ref + 2e-3 (max-abs over the tensor's scale).  These networks
-    contain ReLU / arg-max kinks, and in these deliberately tiny fixtures (a 7x11 bottleneck) one activation within
-    rounding distance of its kink moves a whole tensor by a few per cent under ANY change of summation order; so at
-    most four tensors (two layers' weight + BN bias) may miss the strict bound, and all must meet 10 * err_ref + 5e-3
-    -- the criterion of test_complex_fullwidth_vs_oracle_seeded.  On the direct path, whose accumulation order follows
-    the reference closely, the tight element-wise bound against the fixture (5e-3) is kept as well.  The per-tensor table
-    of the last run is written to gpurun_out/grad_gate_<path>.txt (committed under profiles/)."""
+    Gradient gate (every path, every fixture, every tensor, no exceptions): these networks are piecewise smooth -- a
+    ReLU whose input sits within fp32 rounding of zero may land on either side, and in these deliberately tiny fixtures
+    (a 7x11 bottleneck) one such element moves whole upstream tensors by a few per cent under ANY change of summation
+    order.  Instead of tolerating that, the test replays the ReLU masks the kernels actually used (engine.RELU_CAPTURE)
+    in the oracle run in float64: that is the exact gradient of the piece of the function the HIP path differentiated.
+    Required: err_gpu <= 3 * err_ref + 2e-3 (max-abs over the tensor's scale), where err_ref is the distance of the
+    reference's own fp32 CPU gradients (the fixture) from ITS float64 anchor.  On the direct path, whose accumulation
+    order follows the reference closely, the tight element-wise bound against the fixture itself (5e-3) is kept as
+    well.  The per-tensor table of the last run is written to gpurun_out/grad_gate_<path>.txt (committed under
+    profiles/)."""
     import adam_dehaze_amd.engine as E
     monkeypatch.setattr(E, "USE_WINOGRAD", bool(wino))
     monkeypatch.setattr(E, "USE_WINO43", wino != 23)
@@ -162,29 +167,31 @@ def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
     from adam_dehaze_amd.loss import l1_loss
     m = _load_into(ctor(), rec)
     m.train()
-    out = m(x)
-    assert max_abs(out, rec["out_train"]) < OUT_TOL
-    loss = l1_loss(out, t(rec["target"]).to(DEV))
-    assert abs(float(loss) - float(rec["l1"])) < 1e-5
-    loss.backward()
-    g64 = _fp64_fixture_grads(name, rec)
+    with kink_matched(m) as km:
+        out = m(x)
+        assert max_abs(out, rec["out_train"]) < OUT_TOL
+        loss = l1_loss(out, t(rec["target"]).to(DEV))
+        assert abs(float(loss) - float(rec["l1"])) < 1e-5
+        loss.backward()
+    g64_free = _fp64_fixture_grads(name, rec)
+    g64 = _fp64_fixture_grads(name, rec, km.masks())
     path = {False: "direct", True: "f43", 23: "f23"}[wino]
-    bad, worse, tight, lines = [], [], [], []
+    bad, tight, lines = [], [], []
     for pname, p in m.named_parameters():
         ref32 = t(rec["gp_train." + pname]).double()
         ref64 = g64[pname]
         g = (p.grad.cpu() if p.grad is not None else torch.zeros_like(ref32)).double()
         scale = max(float(ref64.abs().max()), 1e-8)
-        err_ref = float((ref32 - ref64).abs().max()) / scale
+        err_ref = float((ref32 - g64_free[pname]).abs().max()) / scale
         err_gpu = float((g - ref64).abs().max()) / scale
-        lines.append(f"{name:14s} {path:6s} {pname:44s} scale {scale:.2e}  err_ref {err_ref:.2e}  err_gpu {err_gpu:.2e}")
+        err_free = float((g - g64_free[pname]).abs().max()) / scale       # without mask replay (informative)
+        lines.append(f"{name:14s} {path:6s} {pname:44s} scale {scale:.2e}  err_ref {err_ref:.2e}  err_gpu {err_gpu:.2e}  "
+                     f"(unmatched kinks: {err_free:.2e})")
         if scale < 1e-6:      # a bias feeding train-mode BatchNorm: the true gradient is exactly 0, both sides hold noise
             assert float(g.abs().max()) < 1e-6, pname
             continue
         if not err_gpu <= 3.0 * err_ref + 2e-3:
             bad.append((pname, err_gpu, err_ref))
-        if not err_gpu <= 10.0 * err_ref + 5e-3:
-            worse.append((pname, err_gpu, err_ref))
         if not wino and not float((g - ref32).abs().max()) < 5e-3 * max(float(ref32.abs().max()), 1e-8) + 2e-7:
             tight.append((pname, err_gpu, err_ref))
     try:
@@ -193,8 +200,7 @@ def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
             f.write("\n".join(lines) + "\n")
     except OSError:
         pass
-    assert not worse, worse[:8]
-    assert len(bad) <= 4, bad[:8]
+    assert not bad, bad[:8]
     assert not tight, tight[:8]
     after = sub_sd(rec, "sd_after_train.")
     for k, v in m.state_dict().items():
