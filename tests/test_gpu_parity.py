@@ -147,7 +147,7 @@ def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
     (a 7x11 bottleneck) one such element moves whole upstream tensors by a few per cent under ANY change of summation
     order.  Instead of tolerating that, the test replays the ReLU masks the kernels actually used (engine.RELU_CAPTURE)
     in the oracle run in float64: that is the exact gradient of the piece of the function the HIP path differentiated.
-    Required: err_gpu <= 3 * err_ref + 2e-3 (max-abs over the tensor's scale), where err_ref is the distance of the
+    Required: err_gpu <= 3 * err_ref + 3e-4 (max-abs over the tensor's scale; measured <= 7e-5 on every path), where err_ref is the distance of the
     reference's own fp32 CPU gradients (the fixture) from ITS float64 anchor.  On the direct path, whose accumulation
     order follows the reference closely, the tight element-wise bound against the fixture itself (5e-3) is kept as
     well.  The per-tensor table of the last run is written to gpurun_out/grad_gate_<path>.txt (committed under
@@ -190,7 +190,7 @@ def test_branches_vs_reference_fixtures(name, ctor, wino, monkeypatch):
         if scale < 1e-6:      # a bias feeding train-mode BatchNorm: the true gradient is exactly 0, both sides hold noise
             assert float(g.abs().max()) < 1e-6, pname
             continue
-        if not err_gpu <= 3.0 * err_ref + 2e-3:
+        if not err_gpu <= 3.0 * err_ref + 3e-4:
             bad.append((pname, err_gpu, err_ref))
         if not wino and not float((g - ref32).abs().max()) < 5e-3 * max(float(ref32.abs().max()), 1e-8) + 2e-7:
             tight.append((pname, err_gpu, err_ref))
@@ -292,12 +292,12 @@ def test_conv_transpose_vs_oracle(N, Cin, Cout, Hh, Ww):
 @pytest.mark.parametrize("algo", ["direct", "f23", "f43", "f43-fwd", "f43-dgrad"])
 def test_complex_fullwidth_vs_oracle_seeded(algo, monkeypatch):
     """Full-width CORUN-Complex (base 96) on a 2x3x64x96 synthetic foggy batch vs the CPU oracle, through the direct
-    kernels, the F(2x2,3x3) and the F(4x4,3x3) Winograd kernels (the default):
-    eval output, train output and L1 loss within 1e-3; parameter gradients of the smooth objective
-    sum(out*g) judged against the oracle run in fp64: this 50-layer random-init train-mode network
-    amplifies fp32 rounding so much that the CPU fp32 oracle itself is several % off the fp64 gradients
-    for some tensors, so the HIP path must be as close to fp64 as the fp32 CPU path is (3x + 2e-3; up to four
-    tensors 10x + 5e-3, see below)."""
+    kernels, the F(2x2,3x3) and the F(4x4,3x3) Winograd kernels (the default): eval output, train output and L1 loss
+    within 1e-3 (north-star), BN buffers, and EVERY parameter gradient of the smooth objective sum(out*g) against the
+    oracle run in float64 with the kernels' own ReLU masks replayed (tests/_util.py kink_matched: this 50-layer
+    random-init train-mode network has thousands of activations within fp32 rounding of their kink; the CPU fp32 oracle
+    itself sits 0.2-1.6 % from its float64 twin for that reason).  Required per tensor: err_gpu <= 3 * err_cpu + 2e-3,
+    err_cpu = distance of the fp32 CPU oracle from the free-running float64 oracle.  No exceptions."""
     import adam_dehaze_amd.engine as E
     from adam_dehaze_amd.loss import l1_loss
     monkeypatch.setattr(E, "USE_WINOGRAD", algo != "direct")
@@ -320,7 +320,7 @@ def test_complex_fullwidth_vs_oracle_seeded(algo, monkeypatch):
         return out.detach(), sd
 
     ref_train, sd32 = oracle(torch.float32)
-    _, sd64 = oracle(torch.float64)
+    _, sd64_free = oracle(torch.float64)
     ref_loss = F.l1_loss(ref_train, clear)
 
     m = m.to(DEV)
@@ -330,12 +330,14 @@ def test_complex_fullwidth_vs_oracle_seeded(algo, monkeypatch):
     assert max_abs(out, ref_eval) < 1e-3
     assert R.psnr(out.cpu(), ref_eval) > 60.0
     m.train()
-    out = m(hazy.to(DEV))
-    assert max_abs(out, ref_train) < 1e-3
-    loss = l1_loss(out, clear.to(DEV))
-    assert abs(float(loss) - float(ref_loss)) < 1e-4
-    out.backward(gout.to(DEV))
-    bad, worse, ntensors = [], [], 0
+    with kink_matched(m) as km:
+        out = m(hazy.to(DEV))
+        assert max_abs(out, ref_train) < 1e-3
+        loss = l1_loss(out, clear.to(DEV))
+        assert abs(float(loss) - float(ref_loss)) < 1e-4
+        out.backward(gout.to(DEV))
+    _, sd64 = oracle_with_masks(lambda: oracle(torch.float64), km.masks())
+    bad, lines = [], []
     for name, p in m.named_parameters():
         g64 = sd64[name].grad
         if g64 is None:
@@ -343,23 +345,20 @@ def test_complex_fullwidth_vs_oracle_seeded(algo, monkeypatch):
         scale = max(float(g64.abs().max()), 1e-6)
         if name.endswith(".bias") and name.split(".")[-2] == "0" and "decoder" in name:
             continue   # ConvTranspose bias feeding train-mode BN: true gradient is exactly 0 (pure noise)
-        err_cpu = float((sd32[name].grad.double() - g64).abs().max()) / scale
+        err_cpu = float((sd32[name].grad.double() - sd64_free[name].grad).abs().max()) / scale
         err_gpu = float((p.grad.cpu().double() - g64).abs().max()) / scale
-        if os.environ.get("ADH_TEST_VERBOSE"):
-            l2c = float((sd32[name].grad.double() - g64).norm() / g64.norm())
-            l2g = float((p.grad.cpu().double() - g64).norm() / g64.norm())
-            print(f"VV {algo} {name:44s} max cpu {err_cpu:.2e} gpu {err_gpu:.2e}   l2 cpu {l2c:.2e} gpu {l2g:.2e}")
-        # strict: as close to fp64 as the CPU fp32 path (3x + 2e-3).  A handful of tensors may miss it: one ReLU or CBAM
-        # arg-max that sits within rounding distance of its kink flips under ANY change of summation order (measured:
-        # reordering the BatchNorm partial sums of the stride-2 layers moves encoder.1.2.conv1's gradients by 4 % on the
-        # F(2x2,3x3) path), so up to four tensors (two layers' weight + BN bias) get the loose bound 10x + 5e-3
+        err_free = float((p.grad.cpu().double() - sd64_free[name].grad).abs().max()) / scale
+        lines.append(f"complex96 {algo:9s} {name:44s} scale {scale:.2e}  err_cpu {err_cpu:.2e}  err_gpu {err_gpu:.2e}  "
+                     f"(unmatched kinks: {err_free:.2e})")
         if not err_gpu <= 3.0 * err_cpu + 2e-3:
             bad.append((name, err_gpu, err_cpu))
-        if not err_gpu <= 10.0 * err_cpu + 5e-3:
-            worse.append((name, err_gpu, err_cpu))
-        ntensors += 1
-    assert not worse, worse[:8]
-    assert len(bad) <= 4, bad[:8]   # two layers' (weight, BN bias) pairs out of ~100 tensors
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", f"grad_gate_fullwidth_{algo}.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    assert not bad, bad[:8]
     for k, v in m.state_dict().items():
         if "running" in k:
             assert max_abs(v, sd32[k]) < 1e-4, k
