@@ -433,66 +433,104 @@ extern "C" int adh_cbam_bwd_c(void* stream, const float* g, int g_cs, const floa
 }
 
 // D: tiny; single block, images processed in order (deterministic weight-gradient accumulation)
-__global__ __launch_bounds__(256) void cbam_bwd_d_kernel(const float* __restrict__ gca_partial, int nblk,
-                                                         const float* __restrict__ ca, const float* __restrict__ pooled,
-                                                         const float* __restrict__ hidden, const float* __restrict__ w1,
-                                                         const float* __restrict__ w2, int N, int C, int Ch,
-                                                         float* __restrict__ gpool, float* dw1, float* dw2,
-                                                         int accumulate) {
-    extern __shared__ float sm[];
-    float* gpre = sm;            // [C]
-    float* ghid = sm + C;        // [2][Ch]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int n = 0; n < N; ++n) {
-        // g_pre[c] = (sum_blk partial) * ca*(1-ca)
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            double s = 0.0;
-            for (int b = 0; b < nblk; ++b) s += (double)gca_partial[((size_t)n * nblk + b) * C + c];
-            const float a = ca[(size_t)n * C + c];
-            gpre[c] = (float)s * a * (1.f - a);
-        }
-        __syncthreads();
-        // hidden grads (through W2 and the relu masks)
-        for (int o = wave; o < 2 * Ch; o += nw) {
-            const int which = o / Ch, j = o - which * Ch;
-            float acc = 0.f;
-            for (int c = lane; c < C; c += 64) acc += w2[(size_t)c * Ch + j] * gpre[c];
-            acc = wave_sum(acc);
-            if (lane == 0) ghid[o] = hidden[(size_t)n * 2 * Ch + o] > 0.f ? acc : 0.f;
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            float ga = 0.f, gm = 0.f;
-            for (int j = 0; j < Ch; ++j) {
-                const float w = w1[(size_t)j * C + c];
-                ga += w * ghid[j];
-                gm += w * ghid[Ch + j];
-            }
-            gpool[((size_t)n * 2 + 0) * C + c] = ga;
-            gpool[((size_t)n * 2 + 1) * C + c] = gm;
-        }
-        // weight grads
-        const bool first = (n == 0) && !accumulate;
-        for (int i = threadIdx.x; i < C * Ch; i += blockDim.x) {
-            const int c = i / Ch, j = i - c * Ch;  // dw2 [C][Ch]
-            const float v = gpre[c] * (hidden[(size_t)n * 2 * Ch + j] + hidden[(size_t)n * 2 * Ch + Ch + j]);
-            dw2[i] = first ? v : dw2[i] + v;
-        }
-        for (int i = threadIdx.x; i < Ch * C; i += blockDim.x) {
-            const int j = i / C, c = i - j * C;  // dw1 [Ch][C]
-            const float v = ghid[j] * pooled[((size_t)n * 2 + 0) * C + c] + ghid[Ch + j] * pooled[((size_t)n * 2 + 1) * C + c];
-            dw1[i] = first ? v : dw1[i] + v;
-        }
-        __syncthreads();
+// pass D in three small launches instead of one serial workgroup (which walked N images x nblk partials per thread:
+// 0.6 ms of pure latency at HW = 524 288):
+//   d1: gpre[n][c] = (sum_blk gca_partial) * ca (1 - ca)      grid (C/32, N), 8 partial streams per channel in flight
+//   d2: per image: hidden gradients through W2 and the ReLU masks, gpool through W1        grid N
+//   d3: dW1, dW2 = sum over images in a fixed order (deterministic)                        grid ceil(2 C Ch / 256)
+// scratch: gpre [N][C] | ghid [N][2][Ch]
+__global__ __launch_bounds__(256) void cbam_bwd_d1_kernel(const float* __restrict__ gca_partial, int nblk,
+                                                          const float* __restrict__ ca, int C, float* __restrict__ gpre) {
+    __shared__ double red[8][32];
+    const int n = blockIdx.y;
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0;
+    if (c < C)
+        for (int b = grp; b < nblk; b += 8) s += (double)gca_partial[((size_t)n * nblk + b) * C + c];
+    red[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][cl];
+        const float a = ca[(size_t)n * C + c];
+        gpre[(size_t)n * C + c] = (float)t * a * (1.f - a);
     }
 }
 
+__global__ __launch_bounds__(256) void cbam_bwd_d2_kernel(const float* __restrict__ gpre_all, const float* __restrict__ hidden,
+                                                          const float* __restrict__ w1, const float* __restrict__ w2, int C,
+                                                          int Ch, float* __restrict__ ghid_all, float* __restrict__ gpool) {
+    extern __shared__ float sm[];
+    float* gpre = sm;            // [C]
+    float* ghid = sm + C;        // [2][Ch]
+    const int n = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) gpre[c] = gpre_all[(size_t)n * C + c];
+    __syncthreads();
+    for (int o = wave; o < 2 * Ch; o += nw) {
+        const int which = o / Ch, j = o - which * Ch;
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += w2[(size_t)c * Ch + j] * gpre[c];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float v = hidden[(size_t)n * 2 * Ch + o] > 0.f ? acc : 0.f;
+            ghid[o] = v;
+            ghid_all[(size_t)n * 2 * Ch + o] = v;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float ga = 0.f, gm = 0.f;
+        for (int j = 0; j < Ch; ++j) {
+            const float w = w1[(size_t)j * C + c];
+            ga += w * ghid[j];
+            gm += w * ghid[Ch + j];
+        }
+        gpool[((size_t)n * 2 + 0) * C + c] = ga;
+        gpool[((size_t)n * 2 + 1) * C + c] = gm;
+    }
+}
+
+__global__ __launch_bounds__(256) void cbam_bwd_d3_kernel(const float* __restrict__ gpre, const float* __restrict__ ghid,
+                                                          const float* __restrict__ pooled, const float* __restrict__ hidden,
+                                                          int N, int C, int Ch, float* dw1, float* dw2, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = C * Ch;
+    if (i < total) {            // dw2 [C][Ch]
+        const int c = i / Ch, j = i - c * Ch;
+        float v = 0.f;
+        for (int n = 0; n < N; ++n)
+            v += gpre[(size_t)n * C + c] * (hidden[(size_t)n * 2 * Ch + j] + hidden[(size_t)n * 2 * Ch + Ch + j]);
+        dw2[i] = accumulate ? dw2[i] + v : v;
+    } else if (i < 2 * total) {   // dw1 [Ch][C]
+        const int k = i - total;
+        const int j = k / C, c = k - j * C;
+        float v = 0.f;
+        for (int n = 0; n < N; ++n)
+            v += ghid[(size_t)n * 2 * Ch + j] * pooled[((size_t)n * 2 + 0) * C + c] +
+                 ghid[(size_t)n * 2 * Ch + Ch + j] * pooled[((size_t)n * 2 + 1) * C + c];
+        dw1[k] = accumulate ? dw1[k] + v : v;
+    }
+}
+
+extern "C" int adh_cbam_bwd_d_scratch_floats(int N, int C, int Ch) { return N * (C + 2 * Ch); }
+
 extern "C" int adh_cbam_bwd_d(void* stream, const float* gca_partial, int nblk, const float* ca, const float* pooled,
                               const float* hidden, const float* w1, const float* w2, int N, int C, int Ch, float* gpool,
-                              float* dw1, float* dw2, int accumulate) {
-    if (!gca_partial || !ca || !pooled || !hidden || !w1 || !w2 || !gpool || !dw1 || !dw2) return ADH_E_ARG;
-    hipLaunchKernelGGL(cbam_bwd_d_kernel, dim3(1), dim3(256), (C + 2 * Ch) * sizeof(float), (hipStream_t)stream,
-                       gca_partial, nblk, ca, pooled, hidden, w1, w2, N, C, Ch, gpool, dw1, dw2, accumulate);
+                              float* dw1, float* dw2, int accumulate, float* scratch) {
+    if (!gca_partial || !ca || !pooled || !hidden || !w1 || !w2 || !gpool || !dw1 || !dw2 || !scratch || N < 1 || C < 1 ||
+        Ch < 1 || nblk < 1 || N > 65535)
+        return ADH_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    float* gpre = scratch;
+    float* ghid = scratch + (size_t)N * C;
+    hipLaunchKernelGGL(cbam_bwd_d1_kernel, dim3(adh_ceil_div(C, 32), N), dim3(256), 0, s, gca_partial, nblk, ca, C, gpre);
+    hipLaunchKernelGGL(cbam_bwd_d2_kernel, dim3(N), dim3(256), (C + 2 * Ch) * sizeof(float), s, gpre, hidden, w1, w2, C, Ch,
+                       ghid, gpool);
+    hipLaunchKernelGGL(cbam_bwd_d3_kernel, dim3(adh_ceil_div(2 * C * Ch, 256)), dim3(256), 0, s, gpre, ghid, pooled, hidden, N,
+                       C, Ch, dw1, dw2, accumulate);
     return adh_check_launch();
 }
 

@@ -27,6 +27,7 @@
 // Epilogue: accumulators -> LDS M[36][32 tiles][32 co] one channel tile at a time, A^T M A and the fused epilogue.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef W4_DBG
 #define W4_DBG 0   // dev builds (-DW4_DBG=n): 1 = skip the input transform, 2 = skip the contraction, 4 = skip the epilogue, 8 = stage only the first chunk
@@ -51,16 +52,26 @@ struct Wino43Geom {
     int ncog;
 };
 
-template <int IDX>
+// Register class of accumulator tile (frequency FI, channel tile J): 16 tiles fit the 256 AGPRs, the other 9*NT - 16 live
+// in VGPRs.  The VGPR-resident ones are those of the channel tiles the epilogue drains FIRST (all of J = 0, then the
+// last frequencies of J = 1), so that its output transform does not run next to 128 live accumulator VGPRs.
+template <int NT, int FI, int J>
+constexpr bool w4_in_agpr() {
+    constexpr int nv = 9 * NT - 16;                      // tiles that must live in VGPRs (<= 0: none)
+    if constexpr (nv <= 0) return true;
+    else if constexpr (nv <= 9) return !(J == 0 && FI >= 9 - nv);
+    else return !(J == 0 || (J == 1 && FI >= 9 - (nv - 9)));
+}
+template <bool AGPR>
 __device__ __forceinline__ void w4_mfma(f32x16& c, float a, float b) {
-    if constexpr (IDX < 16) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    if constexpr (AGPR) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 // one group: local frequency FI, NT output-channel tiles, 4 k-steps
 template <int NT, int FI, int KK, int J>
 __device__ __forceinline__ void w4_group(f32x16 (&acc)[9 * NT], const f32x4& a, const f32x4 (&b)[NT]) {
     if constexpr (KK < 4) {
-        w4_mfma<FI * NT + J>(acc[FI * NT + J], a[KK], b[J][KK]);
+        w4_mfma<w4_in_agpr<NT, FI, J>()>(acc[FI * NT + J], a[KK], b[J][KK]);
         if constexpr (J + 1 < NT) w4_group<NT, FI, KK, J + 1>(acc, a, b);
         else w4_group<NT, FI, KK + 1, 0>(acc, a, b);
     }
@@ -110,6 +121,21 @@ __device__ __forceinline__ void w4_bt_store(f32x4 (&d)[6], float* dst, int strid
     *reinterpret_cast<f32x4*>(dst + 2 * stride) = n.a * q + p;
     *reinterpret_cast<f32x4*>(dst + 3 * stride) = W4_B * s + r;
     *reinterpret_cast<f32x4*>(dst + 4 * stride) = n.b * s + r;
+}
+
+// accumulators of channel tile J -> M[9 wave + FI][tile row 8 (R >> 2) + 2 (R & 3) + h][l31] (h, l31 are in `addr`), straight
+// from the register class they live in (DS instructions take AGPR data operands on gfx950)
+template <int NT, int J, int FI, int R>
+__device__ __forceinline__ void w4_store_m(const f32x16 (&acc)[9 * NT], unsigned addr) {
+    if constexpr (FI < 9) {
+        constexpr int off = (FI * W4_TILES + 8 * (R >> 2) + ((R & 3) << 1)) * 128;
+        if constexpr (w4_in_agpr<NT, FI, J>())
+            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "a"(acc[FI * NT + J][R]), "n"(off) : "memory");
+        else
+            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(acc[FI * NT + J][R]), "n"(off) : "memory");
+        if constexpr (R + 1 < 16) w4_store_m<NT, J, FI, R + 1>(acc, addr);
+        else w4_store_m<NT, J, FI + 1, 0>(acc, addr);
+    }
 }
 
 // runs the 18 groups of one chunk; GI = group index (frequency GI % 9, channel half GI / 9)
@@ -311,35 +337,63 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const int et = tid >> 3, eq = tid & 7;
     const int etp = (et & ~7) | ((et & 3) << 1) | ((et >> 2) & 1);
     const int ey0 = oy0 + 4 * (et >> 3), ex0 = ox0 + 4 * (et & 7);
+    // One code path for full and ragged regions, without per-pixel address arithmetic or exec-mask branches: raw buffer
+    // stores / residual loads whose address is a per-thread byte offset (constant for the region) plus a workgroup-uniform
+    // scalar offset per pixel; a pixel outside the image or a channel quad beyond Cout gets bit 31 of the vector offset
+    // set, which puts it beyond the descriptor's num_records (= the image's bytes < 2^31, checked by wino43_plan): the
+    // hardware drops the store and returns zeros for the load.  (Range checking covers the vector offset only.)
     float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
     const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
-    const bool vec_ok = (d.out_cstride & 3) == 0 && ((uintptr_t)d.out & 15) == 0 &&
-                        (!d.residual || ((d.res_cstride & 3) == 0 && ((uintptr_t)d.residual & 15) == 0));
+    const int o_px = d.out_cstride * 4, o_row = d.OW * o_px;       // byte pitches (workgroup-uniform)
+    const int r_px = d.res_cstride * 4, r_row = d.OW * r_px;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_n, 0, d.OH * o_row, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res_n ? res_n : out_n), 0, res_n ? d.OH * r_row : 0, 0x00020000);
+    const bool ragged = oy0 + 16 > d.OH || ox0 + 32 > d.OW;     // workgroup-uniform
+    const float act_lo = d.act == ADH_ACT_RELU ? 0.f : -INFINITY;   // ReLU as max(v, 0), identity as max(v, -inf)
+    unsigned rowpen[4], colpen[4];
+    float rowf[4], colf[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rowpen[r] = ey0 + r < d.OH ? 0u : 0x80000000u;
+        colpen[r] = ex0 + r < d.OW ? 0u : 0x80000000u;
+        rowf[r] = ey0 + r < d.OH ? 1.f : 0.f;
+        colf[r] = ex0 + r < d.OW ? 1.f : 0.f;
+    }
+    const unsigned o_vbase = (unsigned)((ey0 * d.OW + ex0) * o_px + (co0 + eq * 4) * 4);
+    const unsigned r_vbase = (unsigned)((ey0 * d.OW + ex0) * r_px + (co0 + eq * 4) * 4);
+    const unsigned m_wbase = (unsigned)(((wave * 9) * W4_TILES + h) * 32 + l31) * 4u;   // byte address of M[9 wave][h][l31]
+    const float* const mp = M + etp * 32 + eq * 4;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         __builtin_amdgcn_s_barrier();   // V / raw (first tile) or the previous tile's M fully consumed
-#pragma unroll
-        for (int fi = 0; fi < 9; ++fi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tp = 8 * (r >> 2) + ((r & 3) << 1) + h;   // row of tile (r & 3) + 8 * (r >> 2) + 4 * h
-                M[((wave * 9 + fi) * W4_TILES + tp) * 32 + l31] = acc[fi * NT + j][r];
-            }
+        if (j == 0) w4_store_m<NT, 0, 0, 0>(acc, m_wbase);
+        if (j == 1) w4_store_m<NT, (NT > 1 ? 1 : 0), 0, 0>(acc, m_wbase);
+        if (j == 2) w4_store_m<NT, (NT > 2 ? 2 : 0), 0, 0>(acc, m_wbase);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int cq0 = co0 + j * 32 + eq * 4;
+        const bool quad_ok = cq0 + 3 < d.Cout;             // Cout % 4 == 0 (wino43_plan): a quad is real or padding
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (d.scale && cq0 + e < d.Cout) sc4[e] = d.scale[cq0 + e];
-            if (d.shift && cq0 + e < d.Cout) sh4[e] = d.shift[cq0 + e];
-        }
-        const bool vec = vec_ok && cq0 + 3 < d.Cout;
+        if (d.scale && quad_ok) sc4 = *reinterpret_cast<const f32x4*>(d.scale + cq0);
+        if (d.shift && quad_ok) sh4 = *reinterpret_cast<const f32x4*>(d.shift + cq0);
+        const unsigned chanpen = quad_ok ? 0u : 0x80000000u;
+        const unsigned o_vj = (o_vbase + j * 128) | chanpen, r_vj = (r_vbase + j * 128) | chanpen;
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
-        const float* mp = M + etp * 32 + eq * 4;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 u[2][6];
+            f32x4 rres[8];   // the residual of this half's 2 x 4 pixels, in flight during the transform
+            // (without a residual the descriptor is empty: every load is out of range and returns zeros without touching
+            // memory -- cheaper than a select per element)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    rres[ii * 4 + jj] = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, r_vj | rowpen[2 * half + ii] | colpen[jj],
+                                                                     (2 * half + ii) * r_row + jj * r_px, 0));
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 f32x4 m[6];
@@ -360,31 +414,23 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
                             d34 = u[ii][3] - u[ii][4];
                 const f32x4 y[4] = {u[ii][0] + s12 + s34, W4_A * d12 + W4_B * d34, W4_A2 * s12 + W4_B2 * s34,
                                     W4_A3 * d12 + W4_B3 * d34 + u[ii][5]};
-                const int oy = ey0 + 2 * half + ii;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const int ox = ex0 + jj;
-                    if (oy < d.OH && ox < d.OW) {
-                        f32x4 v = y[jj] * sc4 + sh4;
-                        ssum += v;
-                        ssq += v * v;
-                        const size_t pix = (size_t)oy * d.OW + ox;
-                        if (vec) {
-                            if (res_n) v += *reinterpret_cast<const f32x4*>(res_n + pix * d.res_cstride + cq0);
-                            if (d.act == ADH_ACT_RELU)
-                                v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-                            *reinterpret_cast<f32x4*>(out_n + pix * d.out_cstride + cq0) = v;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (cq0 + e < d.Cout) {
-                                    float ve = v[e];
-                                    if (res_n) ve += res_n[pix * d.res_cstride + cq0 + e];
-                                    if (d.act == ADH_ACT_RELU) ve = fmaxf(ve, 0.f);
-                                    out_n[pix * d.out_cstride + cq0 + e] = ve;
-                                }
+                    f32x4 v = y[jj] * sc4 + sh4;
+                    if (d.stats) {
+                        f32x4 vs = v;
+                        if (ragged) {   // pixels outside the image do not count (a real, workgroup-uniform branch: the asm
+                            vs = v * (rowf[2 * half + ii] * colf[jj]);   // keeps the compiler from turning it into selects)
+                            asm volatile("" : "+v"(vs));
                         }
+                        ssum += vs;
+                        ssq += vs * vs;
                     }
+                    v += rres[ii * 4 + jj];      // zeros without a residual (empty descriptor)
+                    v = {fmaxf(v[0], act_lo), fmaxf(v[1], act_lo), fmaxf(v[2], act_lo), fmaxf(v[3], act_lo)};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc,
+                                                           o_vj | rowpen[2 * half + ii] | colpen[jj],
+                                                           (2 * half + ii) * o_row + jj * o_px, 0);
                 }
             }
         }
@@ -424,7 +470,14 @@ static int wino43_plan(const adh_conv_desc* d, Wino43Geom* g) {
     if (d->out_oy != 0 || d->out_ox != 0 || d->dy0 != -1 || d->dx0 != -1 || d->dstep_y != 1 || d->dstep_x != 1) return 0;
     if (d->Cin % W4_KC != 0 || d->in_cstride % 4 != 0 || d->NcP % 32 != 0) return 0;
     if (d->VH != d->OH || d->VW != d->OW || d->IH != d->OH || d->IW != d->OW) return 0;
-    if ((int64_t)(d->IH + 2) * d->IW * d->in_cstride >= (1ll << 29) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 31)) return 0;
+    if ((int64_t)(d->IH + 2) * d->IW * d->in_cstride >= (1ll << 29)) return 0;
+    // the epilogue stores 16-byte channel quads through a buffer descriptor spanning one image (conv_wino.hip takes the rest)
+    if (d->Cout % 4 != 0 || d->out_cstride % 4 != 0 || ((uintptr_t)d->out & 15) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 29))
+        return 0;
+    if (d->residual && (d->res_cstride % 4 != 0 || ((uintptr_t)d->residual & 15) ||
+                        (int64_t)d->OH * d->OW * d->res_cstride >= (1ll << 29)))
+        return 0;
+    if ((d->scale && ((uintptr_t)d->scale & 15)) || (d->shift && ((uintptr_t)d->shift & 15))) return 0;
     g->tiles_x = adh_ceil_div(d->OW, 32);
     g->tiles_y = adh_ceil_div(d->OH, 16);
     g->nregions = g->tiles_x * g->tiles_y * d->N;

@@ -744,9 +744,10 @@ class Engine:
                        gsmap.data_ptr(), cidx.data_ptr(), N, HW, Cc, gca_partial.data_ptr(), nblk, work=2 * xbytes)
                 gpool = self._f(N, 2, Cc)
                 dw1, dw2 = self.grad_buffer(w1), self.grad_buffer(w2)
+                scratch = self._f(H.value("adh_cbam_bwd_d_scratch_floats", N, Cc, Ch))
                 H.call("adh_cbam_bwd_d", gca_partial.data_ptr(), nblk, ca.data_ptr(), pooled.data_ptr(),
                        hidden.data_ptr(), w1.data_ptr(), w2.data_ptr(), N, Cc, Ch, gpool.data_ptr(), dw1.data_ptr(),
-                       dw2.data_ptr(), 0)
+                       dw2.data_ptr(), 0, scratch.data_ptr())
                 self.add_param_grad(wsp, dwsp)
                 self.add_param_grad(w1, dw1)
                 self.add_param_grad(w2, dw2)

@@ -51,6 +51,28 @@ def synthetic_batch(n, h, w, seed=42):
     return hazy, clear
 
 
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may actually run on.  A GPU box gives a one-GPU job a share
+    of the host (16 cores on this pool) although os.cpu_count() reports the whole machine; asking torch for hundreds of
+    threads inside that share oversubscribes it 10x and measures the scheduler, not the CPU.  ADH_CPU_THREADS overrides."""
+    env = os.environ.get("ADH_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:    # cgroup v2 CPU quota, if any
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p_ = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p_))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
 def cpu_model_string():
     try:
         with open("/proc/cpuinfo") as f:
@@ -77,6 +99,7 @@ def cpu_baseline(h, w, threads):
     hazy, clear = synthetic_batch(1, h, w, seed=7)
     times = []
     for it in range(4):
+        print(f"[bench] cpu_baseline iteration {it} ({threads} threads) ...", file=sys.stderr, flush=True)
         sd = {k: v.clone() for k, v in sd0.items()}
         for k, v in sd.items():
             if v.is_floating_point() and "running" not in k:
@@ -90,6 +113,7 @@ def cpu_baseline(h, w, threads):
             times.append(dt)
     med = statistics.median(times)
     return {"value": 1.0 / med, "unit": "images/sec", "cores": threads, "kind": "port", "cpu_model": cpu_model_string(),
+            "host_logical_cpus": os.cpu_count(),
             "sample": f"1 image {h}x{w}, CORUN-Complex train fwd + L1 + bwd, 1 warm-up + 3 timed iterations, median "
                       f"{med:.2f} s (all: {', '.join(f'{t_:.2f}' for t_ in times)}), torch CPU oracle, {threads} threads"}
 
@@ -479,7 +503,7 @@ def main():
         if not args.no_forward_eval:
             result["forward_eval"] = forward_eval(model, hazy, args, H)
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(args.height, args.width, os.cpu_count() or 1)
+            result["cpu_baseline"] = cpu_baseline(args.height, args.width, host_threads())
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

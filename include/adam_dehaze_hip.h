@@ -246,10 +246,12 @@ int adh_cbam_bwd_b_num_blocks(int N, int H, int W);
 int adh_cbam_bwd_c(void* stream, const float* g, int g_cs, const float* x, int x_cs, const float* sa,
                    const float* gsmap, const int32_t* cidx, int N, int HW, int C,
                    float* gca_partial, int nblk);
-/* pass D (tiny): reduce gca, back through sigmoid + MLP: gpool[n][2][C], dW1/dW2 (+)= */
+/* pass D (tiny, three launches): reduce gca, back through sigmoid + MLP: gpool[n][2][C], dW1/dW2 (+)= ;
+ * scratch: adh_cbam_bwd_d_scratch_floats(N, C, Ch) floats */
+int adh_cbam_bwd_d_scratch_floats(int N, int C, int Ch);
 int adh_cbam_bwd_d(void* stream, const float* gca_partial, int nblk, const float* ca, const float* pooled,
                    const float* hidden, const float* w1, const float* w2, int N, int C, int Ch,
-                   float* gpool, float* dw1, float* dw2, int accumulate);
+                   float* gpool, float* dw1, float* dw2, int accumulate, float* scratch);
 /* pass E: gx = gx1*ca + gpool.avg/HW + gpool.max*[hw==amax_idx] */
 int adh_cbam_bwd_e(void* stream, const float* g, int g_cs, const float* x, int x_cs, const float* ca,
                    const float* sa, const float* gsmap, const int32_t* cidx, const float* gpool,
