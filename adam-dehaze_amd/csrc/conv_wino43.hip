@@ -32,6 +32,9 @@
 #ifndef W4_DBG
 #define W4_DBG 0   // dev builds (-DW4_DBG=n): 1 = skip the input transform, 2 = skip the contraction, 4 = skip the epilogue, 8 = stage only the first chunk
 #endif
+#ifndef W4_STORE_NOPS
+#define W4_STORE_NOPS 1   // wait states - 1 after each epilogue store (see the comment at the store)
+#endif
 #define W4_KC 16
 #define W4_TILES 32
 #define W4_VF (36 * W4_TILES * W4_KC)              // floats of V (73,728 B)
@@ -339,16 +342,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const int ey0 = oy0 + 4 * (et >> 3), ex0 = ox0 + 4 * (et & 7);
     // One code path for full and ragged regions, without per-pixel address arithmetic or exec-mask branches: raw buffer
     // stores / residual loads whose address is a per-thread byte offset (constant for the region) plus a workgroup-uniform
-    // scalar offset per pixel; a pixel outside the image or a channel quad beyond Cout gets bit 31 of the vector offset
-    // set, which puts it beyond the descriptor's num_records (= the image's bytes < 2^31, checked by wino43_plan): the
-    // hardware drops the store and returns zeros for the load.  (Range checking covers the vector offset only.)
+    // scalar offset per pixel.  A pixel outside the image or a channel quad beyond Cout gets bit 31 of its vector offset set.  The hardware's range check is
+    // `vector offset >= num_records - scalar offset` (unsigned), so with num_records = 0x7fffffff such an access is out
+    // of range for every scalar offset (the store is dropped, the load returns zeros), while a real access, whose byte
+    // offset inside the image is below 2^31 (wino43_plan), never is.  (An exact num_records would be wrong here: with a
+    // scalar offset above it the subtraction wraps and nothing is checked.)
     float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
     const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
     const int o_px = d.out_cstride * 4, o_row = d.OW * o_px;       // byte pitches (workgroup-uniform)
     const int r_px = d.res_cstride * 4, r_row = d.OW * r_px;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_n, 0, d.OH * o_row, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_n, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res_n ? res_n : out_n), 0, res_n ? d.OH * r_row : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res_n ? res_n : out_n), 0, 0x7fffffff, 0x00020000);
     const bool ragged = oy0 + 16 > d.OH || ox0 + 32 > d.OW;     // workgroup-uniform
     const float act_lo = d.act == ADH_ACT_RELU ? 0.f : -INFINITY;   // ReLU as max(v, 0), identity as max(v, -inf)
     unsigned rowpen[4], colpen[4];
@@ -385,15 +390,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         for (int half = 0; half < 2; ++half) {
             f32x4 u[2][6];
             f32x4 rres[8];   // the residual of this half's 2 x 4 pixels, in flight during the transform
-            // (without a residual the descriptor is empty: every load is out of range and returns zeros without touching
-            // memory -- cheaper than a select per element)
+            if (res_n) {   // workgroup-uniform; the asm keeps it a branch (the zero-initialised alternative is free)
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+                for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    rres[ii * 4 + jj] = __builtin_bit_cast(
-                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, r_vj | rowpen[2 * half + ii] | colpen[jj],
-                                                                     (2 * half + ii) * r_row + jj * r_px, 0));
+                    for (int jj = 0; jj < 4; ++jj)
+                        rres[ii * 4 + jj] = __builtin_bit_cast(
+                            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, r_vj | rowpen[2 * half + ii] | colpen[jj],
+                                                                         (2 * half + ii) * r_row + jj * r_px, 0));
+                asm volatile("" ::: "memory");
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rres[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 f32x4 m[6];
@@ -431,6 +440,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc,
                                                            o_vj | rowpen[2 * half + ii] | colpen[jj],
                                                            (2 * half + ii) * o_row + jj * o_px, 0);
+                    // gfx950: a 128-bit buffer store whose data VGPRs are overwritten by the next instructions stores the NEW
+                    // values in some lanes even when its soffset is an SGPR (measured: tools/dev_w43_probe.py; LLVM only
+                    // pads the immediate-soffset form, GCNHazardRecognizer "12-dword store hazard")
+                    asm volatile("s_nop %0" ::"n"(W4_STORE_NOPS) : "memory");
                 }
             }
         }
