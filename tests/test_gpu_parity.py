@@ -350,7 +350,7 @@ def test_complex_fullwidth_vs_oracle_seeded(algo, monkeypatch):
         err_free = float((p.grad.cpu().double() - sd64_free[name].grad).abs().max()) / scale
         lines.append(f"complex96 {algo:9s} {name:44s} scale {scale:.2e}  err_cpu {err_cpu:.2e}  err_gpu {err_gpu:.2e}  "
                      f"(unmatched kinks: {err_free:.2e})")
-        if not err_gpu <= 3.0 * err_cpu + 2e-3:
+        if not err_gpu <= 5e-4:          # measured <= 2.2e-4 on every path; the free-running fp32 CPU oracle: up to 2e-2
             bad.append((name, err_gpu, err_cpu))
     try:
         os.makedirs("gpurun_out", exist_ok=True)
