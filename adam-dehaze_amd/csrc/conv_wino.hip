@@ -51,18 +51,40 @@ struct WinoGeom {
     int dbg;                     // ADH_WINO_DEBUG bit 1 (ablation runs only): skip the epilogue
 };
 
-// accumulator tile IDX of a wave: first 16 in AGPRs, rest in VGPRs (see conv_wgrad.hip, wr_mfma)
-template <int IDX>
+// Register class of accumulator tile (FT = frequency * 2 + tile half, channel tile J) of a wave: 16 tiles fit the 256
+// AGPRs, the other 8*NT - 16 (NT = 3: eight) live in VGPRs (see conv_wgrad.hip, wr_mfma) -- those of channel tile 0,
+// which the epilogue drains first, so that its output transform does not run next to 128 live accumulator VGPRs.
+template <int NT, int FT, int J>
+constexpr bool w2_in_agpr() {
+    constexpr int nv = 8 * NT - 16;
+    if constexpr (nv <= 0) return true;
+    else return !(J == 0 && FT >= 8 - nv);
+}
+template <bool AGPR>
 __device__ __forceinline__ void w2_mfma(f32x16& c, float a, float b) {
-    if constexpr (IDX < 16) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    if constexpr (AGPR) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// accumulators of channel tile J -> M[4 wave + F][tile row 8 (R >> 2) + 2 (R & 3) + h + 32 TH][l31] (h, l31 are in `addr`),
+// straight from the register class they live in
+template <int NT, int J, int FT, int R>
+__device__ __forceinline__ void w2_store_m(const f32x16 (&acc)[8 * NT], unsigned addr) {
+    if constexpr (FT < 8) {
+        constexpr int off = ((FT >> 1) * W2_TILES + 8 * (R >> 2) + ((R & 3) << 1) + 32 * (FT & 1)) * 128;
+        if constexpr (w2_in_agpr<NT, FT, J>())
+            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "a"(acc[FT * NT + J][R]), "n"(off) : "memory");
+        else
+            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(acc[FT * NT + J][R]), "n"(off) : "memory");
+        if constexpr (R + 1 < 16) w2_store_m<NT, J, FT, R + 1>(acc, addr);
+        else w2_store_m<NT, J, FT + 1, 0>(acc, addr);
+    }
 }
 
 // one contraction group: local frequency F, both tile halves, NT output-channel tiles, 4 k-steps
 template <int NT, int F, int KK, int TH, int J>
 __device__ __forceinline__ void w2_group(f32x16 (&acc)[8 * NT], const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
     if constexpr (KK < 4) {
-        w2_mfma<(F * 2 + TH) * NT + J>(acc[(F * 2 + TH) * NT + J], a[TH][KK], b[J][KK]);
+        w2_mfma<w2_in_agpr<NT, F * 2 + TH, J>()>(acc[(F * 2 + TH) * NT + J], a[TH][KK], b[J][KK]);
         if constexpr (J + 1 < NT) w2_group<NT, F, KK, TH, J + 1>(acc, a, b);
         else if constexpr (TH == 0) w2_group<NT, F, KK, 1, 0>(acc, a, b);
         else w2_group<NT, F, KK + 1, 0, 0>(acc, a, b);
@@ -754,38 +776,68 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     // channel quad), two tiles each: float4 reads of the 4x4 frequency patch, G^T m G, fused epilogue, 16-byte stores.
     float* M = lds;   // spans V and the raw buffers
     const int eq = tid & 7;
+    // One code path for full and ragged regions, without per-pixel address arithmetic or exec-mask branches (as in
+    // conv_wino43.hip): raw buffer stores / residual loads whose address is a per-thread byte offset plus a
+    // workgroup-uniform scalar offset per pixel; bit 31 of the vector offset marks a pixel outside the virtual grid or a
+    // channel quad beyond Cout -- out of range against num_records = 0x7fffffff whatever the scalar offset, so the store is
+    // dropped and the load returns zeros.
     float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
     const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
-    const bool vec_ok = (d.out_cstride & 3) == 0 && ((uintptr_t)d.out & 15) == 0 &&
-                        (!d.residual || ((d.res_cstride & 3) == 0 && ((uintptr_t)d.residual & 15) == 0));
+    const int o_px = d.out_cstride * 4 * d.out_sx, o_row = d.OW * d.out_cstride * 4 * d.out_sy;   // byte pitches per virtual pixel
+    const int r_px = d.res_cstride * 4 * d.out_sx, r_row = d.OW * d.res_cstride * 4 * d.out_sy;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_n, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res_n ? res_n : out_n), 0, 0x7fffffff, 0x00020000);
+    const bool ragged = vy0 + 12 > d.VH || vx0 + 48 > d.VW;     // workgroup-uniform
+    const float act_lo = d.act == ADH_ACT_RELU ? 0.f : -INFINITY;   // ReLU as max(v, 0), identity as max(v, -inf)
+    const unsigned m_wbase = (unsigned)(((wave * 4) * W2_TILES + h) * 32 + l31) * 4u;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         __builtin_amdgcn_s_barrier();   // V / raw (first tile) or the previous tile's M fully consumed
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int th = 0; th < 2; ++th)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int tp = 8 * (r >> 2) + ((r & 3) << 1) + h + 32 * th;   // row of tile (r&3) + 8*(r>>2) + 4*h + 32*th
-                    M[((wave * 4 + f) * W2_TILES + tp) * 32 + l31] = acc[(f * 2 + th) * NT + j][r];
-                }
+        if (j == 0) w2_store_m<NT, 0, 0, 0>(acc, m_wbase);
+        if (j == 1) w2_store_m<NT, (NT > 1 ? 1 : 0), 0, 0>(acc, m_wbase);
+        if (j == 2) w2_store_m<NT, (NT > 2 ? 2 : 0), 0, 0>(acc, m_wbase);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int cq0 = co0 + j * 32 + eq * 4;
+        const bool quad_ok = cq0 + 3 < d.Cout;             // Cout % 4 == 0 (wino32_plan): a quad is real or padding
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (d.scale && cq0 + e < d.Cout) sc4[e] = d.scale[cq0 + e];
-            if (d.shift && cq0 + e < d.Cout) sh4[e] = d.shift[cq0 + e];
-        }
-        const bool vec = vec_ok && cq0 + 3 < d.Cout;
+        if (d.scale && quad_ok) sc4 = *reinterpret_cast<const f32x4*>(d.scale + cq0);
+        if (d.shift && quad_ok) sh4 = *reinterpret_cast<const f32x4*>(d.shift + cq0);
+        const unsigned chanpen = quad_ok ? 0u : 0x80000000u;
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int t = (tid >> 3) + 32 * p;                       // tile: row t >> 4, column t & 15
             const int tp = (t & ~7) | ((t & 3) << 1) | ((t >> 2) & 1);
             const float* mp = M + tp * 32 + eq * 4;
+            const int vyb = vy0 + 3 * (t >> 4), vxb = vx0 + 3 * (t & 15);
+            unsigned rowpen[3], colpen[3];
+            float rowf[3], colf[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                rowpen[r] = vyb + r < d.VH ? 0u : 0x80000000u;
+                colpen[r] = vxb + r < d.VW ? 0u : 0x80000000u;
+                rowf[r] = vyb + r < d.VH ? 1.f : 0.f;
+                colf[r] = vxb + r < d.VW ? 1.f : 0.f;
+            }
+            const int pix0 = (vyb * d.out_sy + d.out_oy) * d.OW + vxb * d.out_sx + d.out_ox;
+            const unsigned o_vj = (unsigned)(pix0 * d.out_cstride * 4 + cq0 * 4) | chanpen;
+            const unsigned r_vj = (unsigned)(pix0 * d.res_cstride * 4 + cq0 * 4) | chanpen;
+            f32x4 rres[9];
+            if (res_n) {   // workgroup-uniform; the asm keeps it a branch
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj)
+                        rres[i * 3 + jj] = __builtin_bit_cast(
+                            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, r_vj | rowpen[i] | colpen[jj], i * r_row + jj * r_px, 0));
+                asm volatile("" ::: "memory");
+            } else {
+#pragma unroll
+                for (int q2 = 0; q2 < 9; ++q2) rres[q2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             // u[i][b] = sum_a G^T[i][a] m[a][b],  G^T = [[1, 1/2, 1/2, 0], [0, 1/2, -1/2, 0], [0, 1/2, 1/2, 1]]
             f32x4 u[3][4];
 #pragma unroll
@@ -798,36 +850,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
                 u[1][b2] = hd;
                 u[2][b2] = hs + m[3];
             }
-            const int vyb = vy0 + 3 * (t >> 4), vxb = vx0 + 3 * (t & 15);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const f32x4 hs = 0.5f * (u[i][1] + u[i][2]), hd = 0.5f * (u[i][1] - u[i][2]);
                 const f32x4 y[3] = {u[i][0] + hs, hd, hs + u[i][3]};
-                const int vy = vyb + i;
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) {
-                    const int vx = vxb + jj;
-                    if (vy < d.VH && vx < d.VW) {
-                        f32x4 v = y[jj] * sc4 + sh4;
-                        ssum += v;
-                        ssq += v * v;
-                        const size_t pix = (size_t)(vy * d.out_sy + d.out_oy) * d.OW + (vx * d.out_sx + d.out_ox);
-                        if (vec) {
-                            if (res_n) v += *reinterpret_cast<const f32x4*>(res_n + pix * d.res_cstride + cq0);
-                            if (d.act == ADH_ACT_RELU)
-                                v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-                            *reinterpret_cast<f32x4*>(out_n + pix * d.out_cstride + cq0) = v;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (cq0 + e < d.Cout) {
-                                    float ve = v[e];
-                                    if (res_n) ve += res_n[pix * d.res_cstride + cq0 + e];
-                                    if (d.act == ADH_ACT_RELU) ve = fmaxf(ve, 0.f);
-                                    out_n[pix * d.out_cstride + cq0 + e] = ve;
-                                }
+                    f32x4 v = y[jj] * sc4 + sh4;
+                    if (d.stats) {
+                        f32x4 vs = v;
+                        if (ragged) {   // pixels outside the virtual grid do not count (a real, workgroup-uniform branch)
+                            vs = v * (rowf[i] * colf[jj]);
+                            asm volatile("" : "+v"(vs));
                         }
+                        ssum += vs;
+                        ssq += vs * vs;
                     }
+                    v += rres[i * 3 + jj];
+                    v = {fmaxf(v[0], act_lo), fmaxf(v[1], act_lo), fmaxf(v[2], act_lo), fmaxf(v[3], act_lo)};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, o_vj | rowpen[i] | colpen[jj],
+                                                           i * o_row + jj * o_px, 0);
+                    // gfx950 128-bit buffer-store data hazard (conv_wino43.hip, W4_STORE_NOPS): the asm reads the data
+                    // registers, so they stay untouched until the wait states behind the store have passed
+                    asm volatile("s_nop 1" : "+v"(v)::"memory");
                 }
             }
         }
@@ -866,8 +911,14 @@ static int wino32_plan(const adh_conv_desc* d, Wino32Geom* g) {
     if (!enabled || !d) return 0;
     if (d->Cin % W2_KC != 0 || d->in_cstride % 4 != 0 || d->NcP % 32 != 0) return 0;
     if (d->in_sy != d->in_sx || d->dstep_y != d->dstep_x || d->out_sy != d->out_sx) return 0;
-    if ((int64_t)(d->IH + 2) * d->IW * d->in_cstride >= (1ll << 29) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 31))
+    if ((int64_t)(d->IH + 2) * d->IW * d->in_cstride >= (1ll << 29)) return 0;
+    // the epilogue stores 16-byte channel quads through a buffer descriptor spanning one image (conv_rows.hip takes the rest)
+    if (d->Cout % 4 != 0 || d->out_cstride % 4 != 0 || ((uintptr_t)d->out & 15) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 29))
         return 0;
+    if (d->residual && (d->res_cstride % 4 != 0 || ((uintptr_t)d->residual & 15) ||
+                        (int64_t)d->OH * d->OW * d->res_cstride >= (1ll << 29)))
+        return 0;
+    if ((d->scale && ((uintptr_t)d->scale & 15)) || (d->shift && ((uintptr_t)d->shift & 15))) return 0;
     if (d->KH == 2 && d->KW == 2 && d->dstep_y == d->in_sy && (d->in_sy == 1 || d->in_sy == 2)) {
         g->ncls = 1; g->xps = d->in_sy;
         for (int c = 0; c < 4; ++c) { g->ymin[c] = d->dy0; g->xmin[c] = d->dx0; }
