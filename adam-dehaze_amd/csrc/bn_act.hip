@@ -98,6 +98,25 @@ extern "C" int adh_bn_fold_eval(void* stream, int C, const float* gamma, const f
     return adh_check_launch();
 }
 
+// eval-mode (frozen statistics) BatchNorm backward helpers: with out_pre = gamma*xhat + beta the normalised input is
+// xhat = (out_pre - beta) / gamma, so the train-mode reduction kernels give d-gamma / d-beta when fed y := out_pre,
+// mean := beta, invstd := 1/gamma (0 where gamma == 0: xhat cannot be recovered there and d-gamma reads 0)
+__global__ void bn_eval_bwd_vectors_kernel(int C, int C4, const float* gamma, const float* beta, float* mean, float* invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C4) return;
+    const float g = c < C ? gamma[c] : 0.f;
+    mean[c] = c < C ? beta[c] : 0.f;
+    invstd[c] = g != 0.f ? 1.0f / g : 0.f;
+}
+
+extern "C" int adh_bn_eval_bwd_vectors(void* stream, int C, int C4, const float* gamma, const float* beta, float* mean,
+                                       float* invstd) {
+    if (C < 1 || C4 < C || !gamma || !beta || !mean || !invstd) return ADH_E_ARG;
+    hipLaunchKernelGGL(bn_eval_bwd_vectors_kernel, dim3(adh_ceil_div(C4, 256)), dim3(256), 0, (hipStream_t)stream, C, C4, gamma,
+                       beta, mean, invstd);
+    return adh_check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------
 // apply: out = act(y*scale + shift (+ residual))
 // ---------------------------------------------------------------------------------------------

@@ -614,9 +614,9 @@ class Engine:
             RELU_CAPTURE[id(w)] = out
         if self.record:
             # the parameters _conv_backward will produce a gradient for (must mirror its add_param_grad calls)
+            bn_grads = bn is not None and (training or bn.weight.requires_grad or bn.bias.requires_grad)
             self.use_param(w if (w.requires_grad or self.alias.get(id(w)) is not None) else None, b,
-                           bn.weight if (bn is not None and training) else None,
-                           bn.bias if (bn is not None and training) else None)
+                           bn.weight if bn_grads else None, bn.bias if bn_grads else None)
             self.tape.append(lambda: self._conv_backward(x, w, b, bn, kind, k, stride, pad, relu, residual, o, saved))
         return o
 
@@ -670,10 +670,32 @@ class Engine:
             H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, None, 0, None, None,
                    coef.data_ptr(), 0, g_y.data_ptr(), g_y.stride(2), H.ptr(g_res),
                    g_res.stride(2) if g_res is not None else 0, P, C4, None)
-            if mode == "eval":
-                # frozen-statistics BN: dgamma = sum(g*xhat), dbeta = sum(g); xhat recovered from the conv output is
-                # not kept in eval mode, so only dbeta/dbias are produced (enough for the eval-mode fixtures).
-                pass
+            if mode == "eval" and (bn.weight.requires_grad or bn.bias.requires_grad):
+                # frozen-statistics BN (fine-tuning under module.eval()): dbeta = sum(g'), dgamma = sum(g' * xhat) with
+                # xhat = (out_pre - beta) / gamma recovered from the block output (where the ReLU mask is off g' is 0 and
+                # xhat does not matter); the train-mode reduction kernels do the sums
+                pre = o.t
+                if residual is not None:     # out_pre = out - residual (rare path: one extra pass)
+                    pre = o.t[..., :C4].clone() if o.t.shape[3] >= C4 and o.t[..., :C4].is_contiguous() else None
+                    if pre is None:
+                        pre = self._f(N, OH, OW, C4)
+                        H.call("adh_axpby_strided", pre.data_ptr(), C4, o.t.data_ptr(), o.cs, P, C4, 0.0, 1.0)
+                    H.call("adh_axpby_strided", pre.data_ptr(), pre.stride(2), residual.t.data_ptr(), residual.cs, P, C4,
+                           1.0, -1.0)
+                vmean, vinv = self._f(C4), self._f(C4)
+                H.call("adh_bn_eval_bwd_vectors", Cout, C4, bn.weight.data_ptr(), bn.bias.data_ptr(), vmean.data_ptr(),
+                       vinv.data_ptr())
+                nblk = H.value("adh_bn_bwd_num_blocks", P, C4)
+                partial = self._f(nblk, 2, C4)
+                H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, pre.data_ptr(),
+                       pre.stride(2), vmean.data_ptr(), vinv.data_ptr(), partial.data_ptr(), P, C4, None)
+                dgamma, dbeta, scratch = self._f(C4), self._f(C4), self._f(3, C4)
+                ones = self._f(C4)
+                ones.fill_(1.0)
+                H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), ones.data_ptr(), ones.data_ptr(),
+                       dgamma.data_ptr(), dbeta.data_ptr(), 0, scratch.data_ptr())
+                self.add_param_grad(bn.weight, dgamma[:Cout])
+                self.add_param_grad(bn.bias, dbeta[:Cout])
             if b is not None:
                 self.add_param_grad(b, self._channel_sum(g_y, Cout))
         if g_res is not None:

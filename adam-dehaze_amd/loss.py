@@ -8,12 +8,25 @@ start randomly initialised (load real ones with load_state_dict).
 """
 from __future__ import annotations
 
+import warnings
 from typing import Optional
 
 import torch
 import torch.nn as nn
 
 from . import _hip as H
+
+_WARNED = set()
+
+
+def _warn_random_extractor(what: str, how: str):
+    """The reference builds these feature extractors with pretrained weights (loss.py:20-22,91); they cannot be
+    downloaded here, so the networks start randomly initialised -- say so once, loudly, instead of silently optimising
+    0.1 * content + 0.1 * perceptual against random features."""
+    if what not in _WARNED:
+        _WARNED.add(what)
+        warnings.warn(f"{what}: pretrained weights are not available offline -- the feature extractor is RANDOMLY "
+                      f"initialised until real weights are loaded ({how}).", stacklevel=3)
 
 
 class _L1Fn(torch.autograd.Function):
@@ -190,6 +203,30 @@ class ContentLoss(nn.Module):
         for p in self.model.parameters():
             p.requires_grad = False
         self.tap_indices = [self.LAYER_MAPPING[n] for n in content_layers]
+        self.weights_loaded = False
+        _warn_random_extractor(f"ContentLoss({pretrained_model})", "ContentLoss.load_torchvision_vgg(path_or_state_dict)")
+
+    def load_torchvision_vgg(self, src):
+        """Load a stock torchvision VGG checkpoint (`features.{idx}.weight/bias`, classifier keys ignored) or a state_dict
+        in this module's own naming (`model.{idx}.*`).  `src`: path or dict."""
+        sd = torch.load(src, map_location="cpu") if isinstance(src, (str, bytes)) or hasattr(src, "__fspath__") else src
+        if "state_dict" in sd and isinstance(sd["state_dict"], dict):
+            sd = sd["state_dict"]
+        out = {}
+        for k, v in sd.items():
+            if k.startswith("features."):
+                out["model." + k[len("features."):]] = v
+            elif k.startswith("model."):
+                out[k] = v
+        mine = self.state_dict()
+        missing = [k for k in mine if k not in out]
+        if missing:
+            raise KeyError(f"VGG checkpoint lacks {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        self.load_state_dict({k: out[k] for k in mine}, strict=True)
+        self.weights_loaded = True
+        from .engine import invalidate_weight_cache
+        invalidate_weight_cache()
+        return self
 
     def _features(self, eng, img, taps, holder):
         h = eng.image_normalize_to_nhwc8(img, IMAGENET_MEAN, IMAGENET_STD, holder)
@@ -326,6 +363,48 @@ class PerceptualLoss(nn.Module):
         if net != "alex":
             raise ValueError(f"Unsupported LPIPS net: {net}")
         self.loss_fn = _LPIPSAlex()
+        self.weights_loaded = False
+        _warn_random_extractor("PerceptualLoss(LPIPS-alex)", "PerceptualLoss.load_lpips(alexnet_sd, lpips_linear_sd)")
+
+    def load_lpips(self, alexnet, linear=None):
+        """Load real LPIPS weights: `alexnet` = torchvision alexnet checkpoint (`features.{idx}.*`) or lpips' own
+        `net.slice{k}.{idx}.*` keys; `linear` = lpips' v0.1 `alex.pth` (`lin{k}.model.1.weight`), optional if `alexnet`
+        already is a full lpips state_dict.  Paths or dicts."""
+        def _sd(x):
+            return torch.load(x, map_location="cpu") if isinstance(x, (str, bytes)) or hasattr(x, "__fspath__") else x
+        a = _sd(alexnet)
+        slice_of = {0: 1, 3: 2, 6: 3, 8: 4, 10: 5}
+        out = {}
+        for k, v in a.items():
+            if k.startswith("features."):
+                idx, leaf = k[len("features."):].split(".", 1)
+                if int(idx) in slice_of:
+                    out[f"loss_fn.net.slice{slice_of[int(idx)]}.{idx}.{leaf}"] = v
+            elif k.startswith(("net.", "lin", "scaling_layer.")):
+                out["loss_fn." + k] = v
+            elif k.startswith("loss_fn."):
+                out[k] = v
+        if linear is not None:
+            for k, v in _sd(linear).items():
+                if k.startswith("lin"):
+                    out["loss_fn." + k] = v
+                    out["loss_fn.lins." + k[3] + k[4:]] = v
+        mine = self.state_dict()
+        for k in mine:
+            if k not in out and k.startswith("loss_fn.lins."):
+                alt = "loss_fn.lin" + k[len("loss_fn.lins."):]
+                if alt in out:
+                    out[k] = out[alt]
+            if k not in out and "scaling_layer" in k:
+                out[k] = mine[k]
+        missing = [k for k in mine if k not in out]
+        if missing:
+            raise KeyError(f"LPIPS checkpoint lacks {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        self.load_state_dict({k: out[k] for k in mine}, strict=True)
+        self.weights_loaded = True
+        from .engine import invalidate_weight_cache
+        invalidate_weight_cache()
+        return self
 
     def _features(self, eng, img, holder):
         import ctypes as C

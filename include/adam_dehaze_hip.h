@@ -195,6 +195,11 @@ int adh_bn_finalize(void* stream, const float* partials, int nblk, int NcP, int 
 int adh_bn_fold_eval(void* stream, int C, const float* gamma, const float* beta,
                      const float* running_mean, const float* running_var, float eps,
                      const float* conv_bias, float* scale, float* shift);
+/* eval-mode BN backward: mean[c] = beta[c], invstd[c] = 1/gamma[c] (0 where gamma is 0), padded to C4 with zeros, so
+ * that adh_bn_bwd_reduce / _finalize on y := the pre-activation output give d-gamma / d-beta of a frozen-statistics
+ * BatchNorm (fine-tuning with module.eval(); base_model.py:15-16 under torch autograd) */
+int adh_bn_eval_bwd_vectors(void* stream, int C, int C4, const float* gamma, const float* beta, float* mean,
+                            float* invstd);
 /* out = act(y*scale[c] + shift[c] (+ residual)) over P pixels */
 int adh_bn_apply(void* stream, const float* y, int y_cs, const float* scale, const float* shift,
                  const float* residual, int res_cs, int act, float* out, int out_cs,
