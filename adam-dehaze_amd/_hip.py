@@ -94,11 +94,11 @@ _SIGNATURES = {
     "adh_bn_finalize": [vp, vp, i32, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp],
     "adh_bn_fold_eval": [vp, i32, vp, vp, vp, vp, f32, vp, vp, vp],
     "adh_bn_eval_bwd_vectors": [vp, i32, i32, vp, vp, vp, vp],
-    "adh_bn_apply": [vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, i64, i32],
+    "adh_bn_apply": [vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, i64, i32, vp],
     "adh_bn_bwd_num_blocks": [i64, i32],
-    "adh_bn_bwd_reduce": [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp],
+    "adh_bn_bwd_reduce": [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp, vp],
     "adh_bn_bwd_finalize": [vp, vp, i32, i32, f64, vp, vp, vp, vp, i32, vp],
-    "adh_bn_bwd_apply": [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i64, i32, vp],
+    "adh_bn_bwd_apply": [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i64, i32, vp, vp],
     "adh_cbam_pool": [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "adh_cbam_pool_num_blocks": [i32],
     "adh_cbam_mlp": [vp, vp, vp, vp, i32, i32, i32, vp, vp],

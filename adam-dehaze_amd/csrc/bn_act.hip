@@ -139,7 +139,8 @@ static int ew_blocks(int64_t P, int CQ) {
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int y_cs,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ residual, int res_cs, int act,
-                                                       float* __restrict__ out, int out_cs, int64_t P, int CQ) {
+                                                       float* __restrict__ out, int out_cs, int64_t P, int CQ,
+                                                       uint8_t* __restrict__ mask_bits) {
     const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int64_t pstep = (int64_t)gridDim.x * 256 / CQ;
     int64_t p = t / CQ;
@@ -162,6 +163,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = fmaf(v[u][j], sc[j], sh[j]);   // (the backward mask below repeats exactly this)
             if (residual) w += r[u];
+            if (mask_bits) {
+                // ReLU mask of this quad as a nibble; quads 2m, 2m+1 of a pixel sit in adjacent lanes (CQ is even) and share
+                // byte (q*CQ + cq) / 2: the backward passes read 1 bit per element instead of `out` (4 bytes)
+                const int nib = (w[0] > 0.f ? 1 : 0) | (w[1] > 0.f ? 2 : 0) | (w[2] > 0.f ? 4 : 0) | (w[3] > 0.f ? 8 : 0);
+                const int hi = __shfl_xor(nib, 1, 64);
+                if (q < P && !(threadIdx.x & 1)) mask_bits[(q * CQ + (c >> 2)) >> 1] = (uint8_t)(nib | (hi << 4));
+            }
             if (act == ADH_ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = fmaxf(w[j], 0.f);
@@ -172,12 +180,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 extern "C" int adh_bn_apply(void* stream, const float* y, int y_cs, const float* scale, const float* shift,
-                            const float* residual, int res_cs, int act, float* out, int out_cs, int64_t P, int C) {
+                            const float* residual, int res_cs, int act, float* out, int out_cs, int64_t P, int C,
+                            uint8_t* mask_bits) {
     if (!y || !scale || !shift || !out || P < 1 || C < 4 || (C & 3) || (y_cs & 3) || (out_cs & 3) || (res_cs & 3))
         return ADH_E_ARG;
     const int CQ = C / 4;
+    if (mask_bits && ((CQ & 1) || act != ADH_ACT_RELU)) return ADH_E_ARG;   // nibble pairs: an even number of quads per pixel
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(P, CQ)), dim3(256), 0, (hipStream_t)stream, y, y_cs, scale, shift,
-                       residual, res_cs, act, out, out_cs, P, CQ);
+                       residual, res_cs, act, out, out_cs, P, CQ, mask_bits);
     return adh_check_launch();
 }
 
@@ -196,7 +206,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ y, int y_cs,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* partials, int64_t P,
-                                                            int C, const float* __restrict__ mask_ss) {
+                                                            int C, const float* __restrict__ mask_ss,
+                                                            const uint8_t* __restrict__ mask_bits) {
     __shared__ f32x4 red[2][256];
     const int CQ = C / 4;
     const int R = 256 / CQ;  // pixel rows handled concurrently
@@ -218,18 +229,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const int64_t p1 = p0 + BNB_PPB < P ? p0 + BNB_PPB : P;
         for (int64_t p = p0 + prow; p < p1; p += 4 * R) {
             f32x4 g[4], o[4], yy[4];
+            int mb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t q = p + u * R < p1 ? p + u * R : p;
                 g[u] = *reinterpret_cast<const f32x4*>(g_out + q * g_cs + c);
-                if (act == ADH_ACT_RELU && !mask_ss) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
+                if (mask_bits) mb[u] = mask_bits[(q * CQ + cq) >> 1] >> (4 * (cq & 1));
+                else if (act == ADH_ACT_RELU && !mask_ss) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
                 yy[u] = *reinterpret_cast<const f32x4*>(y + q * y_cs + c);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (p + u * R < p1) {
                     f32x4 gg = g[u];
-                    if (act == ADH_ACT_RELU) {
+                    if (mask_bits) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gg[j] = ((mb[u] >> j) & 1) ? gg[j] : 0.f;
+                    } else if (act == ADH_ACT_RELU) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float ov = mask_ss ? fmaf(yy[u][j], msc[j], msh[j]) : o[u][j];
@@ -258,11 +274,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 extern "C" int adh_bn_bwd_reduce(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
                                  const float* y, int y_cs, const float* mean, const float* invstd, float* partials,
-                                 int64_t P, int C, const float* mask_ss) {
+                                 int64_t P, int C, const float* mask_ss, const uint8_t* mask_bits) {
     if (!g_out || !y || !mean || !invstd || !partials || P < 1 || C < 4 || (C & 3) || C > 1024) return ADH_E_ARG;
-    if (act == ADH_ACT_RELU && !out && !mask_ss) return ADH_E_ARG;
+    if (act == ADH_ACT_RELU && !out && !mask_ss && !mask_bits) return ADH_E_ARG;
+    if (mask_bits && (((C / 4) & 1) || act != ADH_ACT_RELU)) return ADH_E_ARG;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(adh_bn_bwd_num_blocks(P, C)), dim3(256), 0, (hipStream_t)stream, g_out,
-                       g_cs, out, out_cs, act, y, y_cs, mean, invstd, partials, P, C, mask_ss);
+                       g_cs, out, out_cs, act, y, y_cs, mean, invstd, partials, P, C, mask_ss, mask_bits);
     return adh_check_launch();
 }
 
@@ -324,7 +341,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, int training,
                                                            float* __restrict__ g_y, int gy_cs, float* __restrict__ g_res,
-                                                           int gres_cs, int64_t P, int C, const float* __restrict__ mask_ss) {
+                                                           int gres_cs, int64_t P, int C, const float* __restrict__ mask_ss,
+                                                           const uint8_t* __restrict__ mask_bits) {
     const int CQ = C / 4;
     const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int64_t pstep = (int64_t)gridDim.x * 256 / CQ;
@@ -344,11 +362,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
     for (; p < P; p += EW_UNROLL * pstep) {
         f32x4 g[EW_UNROLL], o[EW_UNROLL], yy[EW_UNROLL];
+        int mb[EW_UNROLL];
 #pragma unroll
         for (int u = 0; u < EW_UNROLL; ++u) {
             const int64_t q = p + u * pstep < P ? p + u * pstep : p;
             g[u] = *reinterpret_cast<const f32x4*>(g_out + q * g_cs + c);
-            if (act == ADH_ACT_RELU && !mask_ss) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
+            if (mask_bits) mb[u] = mask_bits[(q * CQ + (c >> 2)) >> 1] >> (4 * ((c >> 2) & 1));
+            else if (act == ADH_ACT_RELU && !mask_ss) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
             if (training) yy[u] = *reinterpret_cast<const f32x4*>(y + q * y_cs + c);
         }
 #pragma unroll
@@ -356,7 +376,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const int64_t q = p + u * pstep;
             if (q < P) {
                 f32x4 gg = g[u];
-                if (act == ADH_ACT_RELU) {
+                if (mask_bits) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gg[j] = ((mb[u] >> j) & 1) ? gg[j] : 0.f;
+                } else if (act == ADH_ACT_RELU) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float ov = mask_ss ? fmaf(yy[u][j], msc[j], msh[j]) : o[u][j];
@@ -376,12 +399,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 extern "C" int adh_bn_bwd_apply(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
                                 const float* y, int y_cs, const float* mean, const float* invstd, const float* coef,
                                 int training, float* g_y, int gy_cs, float* g_res, int gres_cs, int64_t P, int C,
-                                const float* mask_ss) {
+                                const float* mask_ss, const uint8_t* mask_bits) {
     if (!g_out || !coef || !g_y || P < 1 || C < 4 || (C & 3)) return ADH_E_ARG;
     if (training && (!y || !mean || !invstd)) return ADH_E_ARG;
     if (mask_ss && !(training && act == ADH_ACT_RELU)) return ADH_E_ARG;
-    if (act == ADH_ACT_RELU && !out && !mask_ss) return ADH_E_ARG;
+    if (act == ADH_ACT_RELU && !out && !mask_ss && !mask_bits) return ADH_E_ARG;
+    if (mask_bits && (((C / 4) & 1) || act != ADH_ACT_RELU)) return ADH_E_ARG;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P, C / 4)), dim3(256), 0, (hipStream_t)stream, g_out, g_cs, out, out_cs, act,
-                       y, y_cs, mean, invstd, coef, training, g_y, gy_cs, g_res, gres_cs, P, C, mask_ss);
+                       y, y_cs, mean, invstd, coef, training, g_y, gy_cs, g_res, gres_cs, P, C, mask_ss, mask_bits);
     return adh_check_launch();
 }

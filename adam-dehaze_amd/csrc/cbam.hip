@@ -31,15 +31,27 @@ __global__ __launch_bounds__(256) void cbam_pool_partial_kernel(const float* __r
         const float* xn = x + (size_t)n * HW * x_cs;
         const int p0 = blk * POOL_PPB;
         const int p1 = adh_min_i(p0 + POOL_PPB, HW);
-        for (int p = p0 + prow; p < p1; p += R) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + c);
-            s += v;
+        // eight independent 16-byte loads in flight per lane (HBM-bound: one load per iteration left the pass at 2.4 TB/s)
+        for (int p = p0 + prow; p < p1; p += 8 * R) {
+            f32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (v[j] > m[j]) {
-                    m[j] = v[j];
-                    mi[j] = p;
+            for (int u = 0; u < 8; ++u) {
+                const int q = p + u * R < p1 ? p + u * R : p;
+                v[u] = *reinterpret_cast<const f32x4*>(xn + (size_t)q * x_cs + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = p + u * R;
+                if (q < p1) {
+                    s += v[u];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (v[u][j] > m[j]) {     // strictly greater, ascending q: the first index wins ties
+                            m[j] = v[u][j];
+                            mi[j] = q;
+                        }
                 }
+            }
         }
     }
     rs[threadIdx.x] = s;
@@ -72,28 +84,53 @@ __global__ __launch_bounds__(256) void cbam_pool_partial_kernel(const float* __r
     }
 }
 
-__global__ void cbam_pool_final_kernel(const float* __restrict__ partial, const int32_t* __restrict__ partial_idx,
-                                       int nblk, int HW, int C, float* __restrict__ pooled,
-                                       int32_t* __restrict__ amax_idx) {
+// 256 threads per (image, 32 channels): 8 partial streams per channel, combined through LDS (the serial walk over
+// nblk = HW / 1024 partials by one thread per channel was latency-bound: 0.25 ms at HW = 524 288)
+__global__ __launch_bounds__(256) void cbam_pool_final_kernel(const float* __restrict__ partial,
+                                                              const int32_t* __restrict__ partial_idx, int nblk, int HW, int C,
+                                                              float* __restrict__ pooled, int32_t* __restrict__ amax_idx) {
+    __shared__ double rs[8][32];
+    __shared__ float rm[8][32];
+    __shared__ int ri[8][32];
     const int n = blockIdx.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double S = 0.0;
     float M = -INFINITY;
     int MI = 0x7fffffff;
-    for (int b = 0; b < nblk; ++b) {
-        const size_t base = (size_t)n * nblk + b;
-        S += (double)partial[(base * 2 + 0) * C + c];
-        const float v = partial[(base * 2 + 1) * C + c];
-        const int vi = partial_idx[base * C + c];
-        if (v > M || (v == M && vi < MI)) {
-            M = v;
-            MI = vi;
+    if (c < C)
+        for (int b = grp; b < nblk; b += 8) {
+            const size_t base = (size_t)n * nblk + b;
+            S += (double)partial[(base * 2 + 0) * C + c];
+            const float v = partial[(base * 2 + 1) * C + c];
+            const int vi = partial_idx[base * C + c];
+            if (v > M || (v == M && vi < MI)) {
+                M = v;
+                MI = vi;
+            }
         }
+    rs[grp][cl] = S;
+    rm[grp][cl] = M;
+    ri[grp][cl] = MI;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        double T = 0.0;
+        float Mx = -INFINITY;
+        int Ix = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            T += rs[r][cl];
+            const float v = rm[r][cl];
+            const int vi = ri[r][cl];
+            if (v > Mx || (v == Mx && vi < Ix)) {
+                Mx = v;
+                Ix = vi;
+            }
+        }
+        pooled[((size_t)n * 2 + 0) * C + c] = (float)(T / (double)HW);
+        pooled[((size_t)n * 2 + 1) * C + c] = Mx;
+        amax_idx[(size_t)n * C + c] = Ix;
     }
-    pooled[((size_t)n * 2 + 0) * C + c] = (float)(S / (double)HW);
-    pooled[((size_t)n * 2 + 1) * C + c] = M;
-    amax_idx[(size_t)n * C + c] = MI;
 }
 
 extern "C" int adh_cbam_pool(void* stream, const float* x, int x_cs, int N, int HW, int C, float* partial,
@@ -104,7 +141,7 @@ extern "C" int adh_cbam_pool(void* stream, const float* x, int x_cs, int N, int 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(cbam_pool_partial_kernel, dim3(nblk, N), dim3(256), 0, s, x, x_cs, HW, C, partial, partial_idx,
                        nblk);
-    hipLaunchKernelGGL(cbam_pool_final_kernel, dim3(adh_ceil_div(C, 128), N), dim3(128), 0, s, partial, partial_idx, nblk,
+    hipLaunchKernelGGL(cbam_pool_final_kernel, dim3(adh_ceil_div(C, 32), N), dim3(256), 0, s, partial, partial_idx, nblk,
                        HW, C, pooled, amax_idx);
     return adh_check_launch();
 }
@@ -203,53 +240,95 @@ extern "C" int adh_cbam_spatial_stats(void* stream, const float* x, int x_cs, co
 }
 
 // sa = sigmoid(conv7x7(smap)); out = x*ca*sa.  Block = 64 consecutive pixels of one row.
-__global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict__ x, int x_cs,
-                                                         const float* __restrict__ ca, const float* __restrict__ smap,
-                                                         const float* __restrict__ wsp, int H, int W, int C,
-                                                         float* __restrict__ sa, float* __restrict__ out, int out_cs) {
-    __shared__ float s_sa[64];
+// pass 3a: sa = sigmoid(conv7x7([mean_C, max_C])) -- one thread per pixel, the 2-channel map tile and its halo in LDS
+#define SA_TW 32
+#define SA_TH 8
+__global__ __launch_bounds__(256) void cbam_sa_kernel(const float* __restrict__ smap, const float* __restrict__ wsp, int H,
+                                                      int W, float* __restrict__ sa) {
+    __shared__ float tile[SA_TH + 6][SA_TW + 6][2];
     __shared__ float s_w[98];
-    const int n = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 64;
+    const int n = blockIdx.z, y0 = blockIdx.y * SA_TH, x0 = blockIdx.x * SA_TW;
     if (threadIdx.x < 98) s_w[threadIdx.x] = wsp[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int xx = x0 + threadIdx.x;
-        float v = 0.f;
-        if (xx < W) {
-            const float* sm = smap + (size_t)n * H * W * 2;
-            for (int ky = 0; ky < 7; ++ky) {
-                const int yy = y + ky - 3;
-                if (yy < 0 || yy >= H) continue;
-                for (int kx = 0; kx < 7; ++kx) {
-                    const int xs = xx + kx - 3;
-                    if (xs < 0 || xs >= W) continue;
-                    const float* q = sm + ((size_t)yy * W + xs) * 2;
-                    v += q[0] * s_w[ky * 7 + kx] + q[1] * s_w[49 + ky * 7 + kx];
-                }
-            }
-            v = 1.0f / (1.0f + expf(-v));
-            sa[((size_t)n * H + y) * W + xx] = v;
+    const float* sm = smap + (size_t)n * H * W * 2;
+    for (int i = threadIdx.x; i < (SA_TH + 6) * (SA_TW + 6); i += 256) {
+        const int r = i / (SA_TW + 6), cc = i - r * (SA_TW + 6);
+        const int yy = y0 + r - 3, xx = x0 + cc - 3;
+        float a = 0.f, b = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const float* q = sm + ((size_t)yy * W + xx) * 2;
+            a = q[0];
+            b = q[1];
         }
-        s_sa[threadIdx.x] = v;
+        tile[r][cc][0] = a;
+        tile[r][cc][1] = b;
     }
     __syncthreads();
-    const int CQ = C / 4;
-    const int npx = adh_min_i(64, W - x0);
-    const size_t rowbase = ((size_t)n * H + y) * W + x0;
-    const float* can = ca + (size_t)n * C;
-    for (int item = threadIdx.x; item < npx * CQ; item += 256) {
-        const int p = item / CQ, q = item - p * CQ;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (rowbase + p) * x_cs + q * 4) *
-                        *reinterpret_cast<const f32x4*>(can + q * 4) * s_sa[p];
-        *reinterpret_cast<f32x4*>(out + (rowbase + p) * out_cs + q * 4) = v;
+    const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y < H && x < W) {
+        float v = 0.f;
+        // same summation order as the reference's conv2d row walk (ky, kx ascending; channel 0 then 1 per tap)
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx)
+                v += tile[ly + ky][lx + kx][0] * s_w[ky * 7 + kx] + tile[ly + ky][lx + kx][1] * s_w[49 + ky * 7 + kx];
+        sa[((size_t)n * H + y) * W + x] = 1.0f / (1.0f + expf(-v));
     }
+}
+
+// pass 3b: out = x * ca[c] * sa[p] -- streaming, a thread keeps one channel quad (cbam_scale layout = bn_act.hip's):
+// the launch has T threads, T a multiple of CQ; thread t walks pixels t / CQ, + T / CQ, ... eight at a time
+__global__ __launch_bounds__(256) void cbam_scale_kernel(const float* __restrict__ x, int x_cs, const float* __restrict__ ca,
+                                                         const float* __restrict__ sa, int64_t HW, int CQ,
+                                                         float* __restrict__ out, int out_cs) {
+    const int n = blockIdx.y;
+    const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t pstep = (int64_t)gridDim.x * 256 / CQ;
+    int64_t p = t / CQ;
+    const int c = (int)(t - p * CQ) * 4;
+    const f32x4 cav = *reinterpret_cast<const f32x4*>(ca + (size_t)n * CQ * 4 + c);
+    const float* xn = x + (size_t)n * HW * x_cs;
+    float* on = out + (size_t)n * HW * out_cs;
+    const float* san = sa + (size_t)n * HW;
+    for (; p < HW; p += 8 * pstep) {
+        f32x4 v[8];
+        float sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t q = p + u * pstep < HW ? p + u * pstep : p;
+            v[u] = *reinterpret_cast<const f32x4*>(xn + q * x_cs + c);
+            sv[u] = san[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t q = p + u * pstep;
+            if (q < HW) *reinterpret_cast<f32x4*>(on + q * out_cs + c) = v[u] * cav * sv[u];
+        }
+    }
+}
+
+static int cbam_scale_blocks(int64_t HW, int CQ) {
+    int g = CQ, r = 256;   // gcd(CQ, 256)
+    while (r) { const int t = g % r; g = r; r = t; }
+    const int mult = CQ / g;
+    int64_t want = (HW * CQ + 256 * 8 - 1) / (256 * 8);
+    if (want > 1024) want = 1024;
+    int64_t blocks = (want + mult - 1) / mult * mult;
+    if (blocks < mult) blocks = mult;
+    return (int)blocks;
 }
 
 extern "C" int adh_cbam_apply(void* stream, const float* x, int x_cs, const float* ca, const float* smap,
                               const float* wsp, int N, int H, int W, int C, float* sa, float* out, int out_cs) {
-    if (!x || !ca || !smap || !wsp || !sa || !out || N < 1 || C < 4 || (C & 3) || H > 65535 || N > 65535) return ADH_E_ARG;
-    hipLaunchKernelGGL(cbam_apply_kernel, dim3(adh_ceil_div(W, 64), H, N), dim3(256), 0, (hipStream_t)stream, x, x_cs, ca,
-                       smap, wsp, H, W, C, sa, out, out_cs);
+    if (!x || !ca || !smap || !wsp || !sa || !out || N < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || (x_cs & 3) || (out_cs & 3) ||
+        N > 65535)
+        return ADH_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cbam_sa_kernel, dim3(adh_ceil_div(W, SA_TW), adh_ceil_div(H, SA_TH), N), dim3(256), 0, s, smap, wsp, H, W,
+                       sa);
+    hipLaunchKernelGGL(cbam_scale_kernel, dim3(cbam_scale_blocks((int64_t)H * W, C / 4), N), dim3(256), 0, s, x, x_cs, ca, sa,
+                       (int64_t)H * W, C / 4, out, out_cs);
     return adh_check_launch();
 }
 

@@ -28,7 +28,8 @@ USE_WINO43 = {"0": False, "1": True}.get(os.environ.get("ADH_WINO43", "1"), os.e
 # F(4x4,3x3)-domain weight gradient (conv_wgrad43.hip): correct and tested, but 15-25 % slower than the F(2x2,3x3)-domain
 # kernel as of round 1 -- opt-in
 USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "0") != "0"
-USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"      # conv_wgrad_small.hip for the few-channel 3x3 layers
+USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"
+USE_RELU_BITS = os.environ.get("ADH_RELU_BITS", "1") != "0"         # bit-packed ReLU mask for the residual BN layers      # conv_wgrad_small.hip for the few-channel 3x3 layers
 _WINO_ONLY = os.environ.get("ADH_WINOGRAD_ONLY", "")   # dev: "fwd" or "dgrad" restricts the Winograd path to one direction
 
 
@@ -551,7 +552,7 @@ class Engine:
         partial = self._f(nblk, 2, C4)
         zeros = self._f(C4, zero=True)
         H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), None, 0, H.ACT_NONE, g.data_ptr(), g.stride(2),
-               zeros.data_ptr(), zeros.data_ptr(), partial.data_ptr(), P, C4, None)
+               zeros.data_ptr(), zeros.data_ptr(), partial.data_ptr(), P, C4, None, None)
         dbeta = self._f(C4)
         coef = self._f(3, C4)
         H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), None, zeros.data_ptr(), None,
@@ -595,10 +596,15 @@ class Engine:
                    scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
+            # residual + ReLU (ResidualBlock tail): the backward ReLU mask cannot be recomputed from y alone; keep it as one
+            # bit per element (1/32 of `out`) written by this pass instead of reading `out` twice in the backward pass
+            mbits = None
+            if USE_RELU_BITS and relu and res_t is not None and self.record and Cout % 8 == 0:
+                mbits = torch.empty((P * Cout + 7) // 8, device=self.device, dtype=torch.uint8)
             H.call("adh_bn_apply", y.data_ptr(), y.stride(2), scale.data_ptr(), shift.data_ptr(), H.ptr(res_t),
-                   res_t.stride(2) if res_t is not None else 0, act_code, out.data_ptr(), out.stride(2), P, Cout,
+                   res_t.stride(2) if res_t is not None else 0, act_code, out.data_ptr(), out.stride(2), P, Cout, H.ptr(mbits),
                    work=4.0 * P * Cout * (3 if res_t is not None else 2))     # bytes: read y (+ residual), write out
-            saved = ("train", y, mean, invstd, ss)
+            saved = ("train", y, mean, invstd, ss, mbits)
         elif bn is not None:
             scale, shift = self._f(Cout), self._f(Cout)
             H.call("adh_bn_fold_eval", Cout, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
@@ -637,15 +643,15 @@ class Engine:
         if residual is not None and residual.needs_grad:
             g_res = self._f(N, OH, OW, C4)
         if mode == "train":
-            _, y, mean, invstd, ss = saved
+            _, y, mean, invstd, ss, mbits = saved
             # without a residual the ReLU mask is recomputed from y (fma(y, scale, shift) > 0, the forward expression):
             # the two backward passes then read two tensors each instead of three
             mask_ss = ss.data_ptr() if (relu and residual is None) else None
             nblk = H.value("adh_bn_bwd_num_blocks", P, C4)
             partial = self._f(nblk, 2, C4)
             H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
-                   y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4, mask_ss,
-                   work=4.0 * P * Cout * (2 if (mask_ss is not None or not relu) else 3))   # bytes: g, y (+ out for the mask)
+                   y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4, mask_ss, H.ptr(mbits),
+                   work=4.0 * P * Cout * (2 if (mask_ss is not None or mbits is not None or not relu) else 3))   # g, y (+ out)
             if C4 == Cout:
                 dgamma, dbeta = self.grad_buffer(bn.weight), self.grad_buffer(bn.bias)
             else:
@@ -655,8 +661,9 @@ class Engine:
                    invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
             H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
                    y.stride(2), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), 1, g_y.data_ptr(), g_y.stride(2),
-                   H.ptr(g_res), g_res.stride(2) if g_res is not None else 0, P, C4, mask_ss,
-                   work=4.0 * P * Cout * ((2 if (mask_ss is not None or not relu) else 3) + 1 + (1 if g_res is not None else 0)))
+                   H.ptr(g_res), g_res.stride(2) if g_res is not None else 0, P, C4, mask_ss, H.ptr(mbits),
+                   work=4.0 * P * Cout * ((2 if (mask_ss is not None or mbits is not None or not relu) else 3) + 1 +
+                                          (1 if g_res is not None else 0)))
             self.add_param_grad(bn.weight, dgamma[:Cout])
             self.add_param_grad(bn.bias, dbeta[:Cout])
             if b is not None:   # a bias feeding train-mode BN has an exactly zero gradient
@@ -669,7 +676,7 @@ class Engine:
                 coef[0].fill_(1.0)
             H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, None, 0, None, None,
                    coef.data_ptr(), 0, g_y.data_ptr(), g_y.stride(2), H.ptr(g_res),
-                   g_res.stride(2) if g_res is not None else 0, P, C4, None)
+                   g_res.stride(2) if g_res is not None else 0, P, C4, None, None)
             if mode == "eval" and (bn.weight.requires_grad or bn.bias.requires_grad):
                 # frozen-statistics BN (fine-tuning under module.eval()): dbeta = sum(g'), dgamma = sum(g' * xhat) with
                 # xhat = (out_pre - beta) / gamma recovered from the block output (where the ReLU mask is off g' is 0 and
@@ -688,7 +695,7 @@ class Engine:
                 nblk = H.value("adh_bn_bwd_num_blocks", P, C4)
                 partial = self._f(nblk, 2, C4)
                 H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, pre.data_ptr(),
-                       pre.stride(2), vmean.data_ptr(), vinv.data_ptr(), partial.data_ptr(), P, C4, None)
+                       pre.stride(2), vmean.data_ptr(), vinv.data_ptr(), partial.data_ptr(), P, C4, None, None)
                 dgamma, dbeta, scratch = self._f(C4), self._f(C4), self._f(3, C4)
                 ones = self._f(C4)
                 ones.fill_(1.0)
@@ -897,7 +904,7 @@ class Engine:
         if out is None:
             out = self._f(N, Hh, Ww, Cc)
         H.call("adh_bn_apply", x.t.data_ptr(), x.cs, scale.data_ptr(), shift.data_ptr(), None, 0, H.ACT_RELU,
-               out.data_ptr(), out.stride(2), x.pixels, Cc)
+               out.data_ptr(), out.stride(2), x.pixels, Cc, None)
         return Act(out, Cc)
 
     def mul_mask(self, x: Act, mask: torch.Tensor) -> Act:

@@ -200,10 +200,11 @@ int adh_bn_fold_eval(void* stream, int C, const float* gamma, const float* beta,
  * BatchNorm (fine-tuning with module.eval(); base_model.py:15-16 under torch autograd) */
 int adh_bn_eval_bwd_vectors(void* stream, int C, int C4, const float* gamma, const float* beta, float* mean,
                             float* invstd);
-/* out = act(y*scale[c] + shift[c] (+ residual)) over P pixels */
+/* out = act(y*scale[c] + shift[c] (+ residual)) over P pixels.  mask_bits (optional, ReLU only, C/4 even): one bit per
+ * element, bit (p*C + c) of the byte array = [pre-activation > 0] -- the backward passes then read this instead of `out` */
 int adh_bn_apply(void* stream, const float* y, int y_cs, const float* scale, const float* shift,
                  const float* residual, int res_cs, int act, float* out, int out_cs,
-                 int64_t P, int C);
+                 int64_t P, int C, uint8_t* mask_bits);
 /* backward of act(BN(y) (+res)): given g_out and the forward output `out` (relu mask),
  * pass 1: per-block partial sums of g and g*xhat -> partials[nblk][2][C]
  * (nblk = adh_bn_bwd_num_blocks(P)). */
@@ -212,7 +213,7 @@ int adh_bn_bwd_num_blocks(int64_t P, int C);
  * recomputed as fma(y, scale, shift) > 0, exactly the forward expression, and `out` is not read (one tensor pass less). */
 int adh_bn_bwd_reduce(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
                       const float* y, int y_cs, const float* mean, const float* invstd,
-                      float* partials, int64_t P, int C, const float* mask_ss);
+                      float* partials, int64_t P, int C, const float* mask_ss, const uint8_t* mask_bits);
 /* finalize: dgamma = sum(g*xhat), dbeta = sum(g) (accumulated into grads when accumulate!=0) and the
  * per-channel coefficients used by pass 2. coef[3][C] = {gamma*invstd, mean_g, mean_gxhat}. */
 int adh_bn_bwd_finalize(void* stream, const float* partials, int nblk, int C, double count,
@@ -223,7 +224,7 @@ int adh_bn_bwd_finalize(void* stream, const float* partials, int nblk, int C, do
 int adh_bn_bwd_apply(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
                      const float* y, int y_cs, const float* mean, const float* invstd, const float* coef,
                      int training, float* g_y, int gy_cs, float* g_res, int gres_cs, int64_t P, int C,
-                     const float* mask_ss);
+                     const float* mask_ss, const uint8_t* mask_bits);
 
 /* ---- AttentionBlock (base_model.py:43-78) ----------------------------------------------------- */
 /* pooled[n][2][C] = (mean, max) over H*W; amax_idx[n][C] = first pixel index attaining the max */

@@ -93,7 +93,7 @@ def main():
         sh = torch.zeros(Cc, device=dev)
 
         def bn_apply():
-            H.call("adh_bn_apply", y.data_ptr(), Cc, sc.data_ptr(), sh.data_ptr(), None, 0, 1, out.data_ptr(), Cc, P, Cc)
+            H.call("adh_bn_apply", y.data_ptr(), Cc, sc.data_ptr(), sh.data_ptr(), None, 0, 1, out.data_ptr(), Cc, P, Cc, None)
         ms = timeit(bn_apply, args.iters)
         print(f"bn_apply 96ch full  {ms:8.3f} ms  {2 * y.numel() * 4 / ms / 1e9:7.2f} TB/s")
         g = torch.randn_like(y)
@@ -106,13 +106,13 @@ def main():
 
         def bn_bwd_reduce():
             H.call("adh_bn_bwd_reduce", g.data_ptr(), Cc, out.data_ptr(), Cc, 1, y.data_ptr(), Cc, mean.data_ptr(),
-                   inv.data_ptr(), part.data_ptr(), P, Cc, None)
+                   inv.data_ptr(), part.data_ptr(), P, Cc, None, None)
         ms = timeit(bn_bwd_reduce, args.iters)
         print(f"bn_bwd_reduce 96ch  {ms:8.3f} ms  {3 * y.numel() * 4 / ms / 1e9:7.2f} TB/s")
 
         def bn_bwd_apply():
             H.call("adh_bn_bwd_apply", g.data_ptr(), Cc, out.data_ptr(), Cc, 1, y.data_ptr(), Cc, mean.data_ptr(),
-                   inv.data_ptr(), coef.data_ptr(), 1, gy.data_ptr(), Cc, None, 0, P, Cc, None)
+                   inv.data_ptr(), coef.data_ptr(), 1, gy.data_ptr(), Cc, None, 0, P, Cc, None, None)
         ms = timeit(bn_bwd_apply, args.iters)
         print(f"bn_bwd_apply 96ch   {ms:8.3f} ms  {4 * y.numel() * 4 / ms / 1e9:7.2f} TB/s")
 

@@ -23,8 +23,8 @@ gx = torch.empty_like(g)
 def wgrad(): eng._wgrad(plans, x, g, Cc, w)
 def dgrad(): eng._run_gather(dplans, Act(g, Cc), gx, Cc, w)
 def bn():
-    H.call("adh_bn_bwd_reduce", g.data_ptr(), Cc, out.data_ptr(), Cc, 1, y.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, Cc, None)
-    H.call("adh_bn_bwd_apply", g.data_ptr(), Cc, out.data_ptr(), Cc, 1, y.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), 1, gy.data_ptr(), Cc, None, 0, P, Cc, None)
+    H.call("adh_bn_bwd_reduce", g.data_ptr(), Cc, out.data_ptr(), Cc, 1, y.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, Cc, None, None)
+    H.call("adh_bn_bwd_apply", g.data_ptr(), Cc, out.data_ptr(), Cc, 1, y.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), 1, gy.data_ptr(), Cc, None, 0, P, Cc, None, None)
 def t(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
