@@ -29,7 +29,11 @@ USE_WINO43 = {"0": False, "1": True}.get(os.environ.get("ADH_WINO43", "1"), os.e
 # kernel as of round 1 -- opt-in
 USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "0") != "0"
 USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"
-USE_RELU_BITS = os.environ.get("ADH_RELU_BITS", "1") != "0"         # bit-packed ReLU mask for the residual BN layers      # conv_wgrad_small.hip for the few-channel 3x3 layers
+# Bit-packed ReLU mask for the residual BN layers (1 bit per element written by bn_apply, read by the two backward passes
+# instead of `out`): correct and tested, but measured SLOWER on MI355X (bench, ms/step: bn_apply 8.19 -> 8.47,
+# bn_bwd_reduce 8.79 -> 9.85, bn_bwd_apply 12.78 -> 12.52; +1.1 ms in all): the byte loads double the number of
+# vector-memory instructions of passes that were already running at 5+ TB/s.  Opt-in (ADH_RELU_BITS=1).
+USE_RELU_BITS = os.environ.get("ADH_RELU_BITS", "0") != "0"      # conv_wgrad_small.hip for the few-channel 3x3 layers
 _WINO_ONLY = os.environ.get("ADH_WINOGRAD_ONLY", "")   # dev: "fwd" or "dgrad" restricts the Winograd path to one direction
 
 

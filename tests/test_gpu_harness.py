@@ -237,3 +237,29 @@ def test_packed_weight_cache_follows_parameter_updates(monkeypatch):
         E.invalidate_weight_cache()
         fresh = m(x)
     assert not torch.equal(before, after) and torch.equal(after, fresh)
+
+
+def test_relu_bitmask_path_matches_default(monkeypatch):
+    """engine.USE_RELU_BITS (opt-in: measured slower, see engine.py): the ResidualBlock tail's backward with the
+    bit-packed ReLU mask gives bit-identical gradients to the default path that reads `out`."""
+    import adam_dehaze_amd.engine as E
+    from adam_dehaze_amd.engine import Act, Engine
+    from adam_dehaze_amd.layers import ResidualBlock
+    torch.manual_seed(0)
+    blk = ResidualBlock(32).to(DEV).train()
+    x = torch.randn(2, 19, 37, 32, device=DEV)
+    gout = torch.randn(2, 19, 37, 32, device=DEV)
+    res = {}
+    for bits in (False, True):
+        monkeypatch.setattr(E, "USE_RELU_BITS", bits)
+        eng = Engine(torch.device(DEV), record=True)
+        xa = Act(x.clone())
+        o = blk.run(eng, xa, True)
+        o.grad = gout.clone()
+        eng.backward()
+        torch.cuda.synchronize()
+        names = {id(p): n for n, p in blk.named_parameters()}
+        res[bits] = (o.t.clone(), xa.grad.clone(), {names[k]: g.clone() for k, g in eng.param_grads.items()})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for k, g in res[False][2].items():
+        assert torch.equal(res[True][2][k], g), k
