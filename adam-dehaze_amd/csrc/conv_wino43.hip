@@ -379,21 +379,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int cq0 = co0 + j * 32 + eq * 4;
-        // a quad with at least one real channel is stored whole: its padding lanes hold exact zeros (zero weights, scale 1,
-        // shift 0), and wino43_plan requires the tensor to own them (out_cstride >= Cout rounded up to 4)
-        const bool quad_ok = cq0 + 3 < d.Cout, quad_any = cq0 < d.Cout;
+        const bool quad_ok = cq0 + 3 < d.Cout;             // Cout % 4 == 0 (wino43_plan): a quad is real or padding
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-        if (quad_ok) {
-            if (d.scale) sc4 = *reinterpret_cast<const f32x4*>(d.scale + cq0);
-            if (d.shift) sh4 = *reinterpret_cast<const f32x4*>(d.shift + cq0);
-        } else if (quad_any) {
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                if (d.scale && cq0 + e < d.Cout) sc4[e] = d.scale[cq0 + e];
-                if (d.shift && cq0 + e < d.Cout) sh4[e] = d.shift[cq0 + e];
-            }
-        }
-        const unsigned chanpen = quad_any ? 0u : 0x80000000u;
+        if (d.scale && quad_ok) sc4 = *reinterpret_cast<const f32x4*>(d.scale + cq0);
+        if (d.shift && quad_ok) sh4 = *reinterpret_cast<const f32x4*>(d.shift + cq0);
+        const unsigned chanpen = quad_ok ? 0u : 0x80000000u;
         const unsigned o_vj = (o_vbase + j * 128) | chanpen, r_vj = (r_vbase + j * 128) | chanpen;
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -497,13 +487,9 @@ static int wino43_plan(const adh_conv_desc* d, Wino43Geom* g) {
     if (d->VH != d->OH || d->VW != d->OW || d->IH != d->OH || d->IW != d->OW) return 0;
     if ((int64_t)(d->IH + 2) * d->IW * d->in_cstride >= (1ll << 29)) return 0;
     // the epilogue stores 16-byte channel quads through a buffer descriptor spanning one image (conv_wino.hip takes the rest)
-    // (Cout % 4 != 0: the last quad is stored / its residual read whole, so the tensors must own the channels up to the next
-    // multiple of 4 -- padding that receives exact zeros; a channel slice of a wider buffer never ends off a quad boundary here)
-    const int cout4 = adh_round_up(d->Cout, 4);
-    if (d->out_cstride % 4 != 0 || d->out_cstride < cout4 || ((uintptr_t)d->out & 15) ||
-        (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 29))
+    if (d->Cout % 4 != 0 || d->out_cstride % 4 != 0 || ((uintptr_t)d->out & 15) || (int64_t)d->OH * d->OW * d->out_cstride >= (1ll << 29))
         return 0;
-    if (d->residual && (d->res_cstride % 4 != 0 || d->res_cstride < cout4 || ((uintptr_t)d->residual & 15) ||
+    if (d->residual && (d->res_cstride % 4 != 0 || ((uintptr_t)d->residual & 15) ||
                         (int64_t)d->OH * d->OW * d->res_cstride >= (1ll << 29)))
         return 0;
     if ((d->scale && ((uintptr_t)d->scale & 15)) || (d->shift && ((uintptr_t)d->shift & 15))) return 0;
