@@ -237,3 +237,23 @@ def test_complex_eval_forward_large_frame_properties():
     assert float(both.min()) >= 0.0 and float(both.max()) <= 1.0
     assert torch.equal(both, again)
     assert max_abs(both[1:2], one) < 1e-6
+
+
+def test_evaluate_joint_model_writes_the_reference_results_json(tmp_path):
+    """evaluation/evaluate.py:94-177 (image-quality part): route synthetic test batches through the joint model,
+    accumulate PSNR / SSIM / LPIPS per intensity category on the device, save joint_model_results.json."""
+    import json
+    cfg = _cfg()
+    cfg["evaluation"] = {"results_dir": str(tmp_path / "results")}
+    cfg["joint_training"]["checkpoint_dir"] = str(tmp_path / "nojoint")
+    torch.manual_seed(6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = T.evaluate_joint_model(cfg, steps=2)
+    saved = json.load(open(tmp_path / "results" / "joint_model_results.json"))
+    assert saved == res and set(saved) <= {"low_intensity", "medium_intensity", "high_intensity"} and len(saved) >= 2
+    n = sum(v["samples"] for v in saved.values())
+    assert n == 8
+    for v in saved.values():
+        assert set(v) == {"psnr", "ssim", "lpips", "samples"}
+        assert 0.0 < v["psnr"] < 100.0 and -1.0 <= v["ssim"] <= 1.0 and v["lpips"] == v["lpips"]
