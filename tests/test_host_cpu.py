@@ -273,3 +273,31 @@ def test_resume_checkpoint_discovery(tmp_path):
     assert find_resume_checkpoint(d).endswith("best_model.pth")       # written later in training than epoch 10
     torch.save({"epoch": 7, "val_psnr": 20.0}, os.path.join(d, "best_model.pth"))
     assert find_resume_checkpoint(d).endswith("checkpoint_epoch_10.pth")
+
+
+def test_loss_extractor_warnings_and_weight_loaders():
+    """the VGG16 / LPIPS extractors start randomly initialised -- say so once; torchvision / lpips checkpoints
+    load through key-remapping helpers (`features.{i}.*` -> `model.{i}.*`; `features.{i}.*` + `lin{k}.model.1.weight` ->
+    `loss_fn.net.slice{k}.{i}.*`, `loss_fn.lin{k}` and `loss_fn.lins.{k}`)."""
+    import warnings
+    import adam_dehaze_amd.loss as L
+    from tests._thirdparty_init import lpips_alex_sd
+    L._WARNED.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        c, pl = L.ContentLoss(), L.PerceptualLoss()
+        L.ContentLoss()                                       # second construction: no second warning
+    msgs = [str(x.message) for x in w]
+    assert len(msgs) == 2 and all("RANDOMLY" in m for m in msgs)
+    tv = {"features." + k[len("model."):]: v.clone() + 1 for k, v in c.state_dict().items()}
+    tv["classifier.0.weight"] = torch.zeros(1)
+    c.load_torchvision_vgg(tv)
+    assert c.weights_loaded and torch.equal(c.state_dict()["model.0.weight"], tv["features.0.weight"])
+    with pytest.raises(KeyError):
+        L.ContentLoss().load_torchvision_vgg({"features.0.weight": torch.zeros(64, 3, 3, 3)})
+    lsd = lpips_alex_sd(0)
+    pl.load_lpips(lsd)
+    alex = {f"features.{k.split('.')[3]}.{k.split('.')[4]}": v for k, v in lsd.items() if ".net.slice" in k}
+    lin = {k[len("loss_fn."):]: v for k, v in lsd.items() if k.startswith("loss_fn.lin") and not k.startswith("loss_fn.lins")}
+    p2 = L.PerceptualLoss().load_lpips(alex, lin)
+    assert p2.weights_loaded and all(torch.equal(p2.state_dict()[k], pl.state_dict()[k]) for k in pl.state_dict())
