@@ -123,7 +123,9 @@ extern "C" int adh_bn_eval_bwd_vectors(void* stream, int C, int C4, const float*
 // Streaming layout shared by the element-wise kernels below: the launch has T = gridDim.x * 256 threads with T a
 // multiple of CQ (channel quads per pixel), so a thread keeps one channel quad for the whole sweep -- its per-channel
 // constants are loaded once and no index division happens inside the loop -- and walks pixels p0, p0 + T/CQ, ...
-// four at a time (4-12 independent 16-byte loads in flight per lane: these kernels are HBM-bound).
+// four at a time (4-12 independent 16-byte loads in flight per lane: these kernels are HBM-bound).  The tensors are
+// far larger than L2 + Infinity Cache and each element is touched once per pass, so all of their loads / stores carry the
+// non-temporal hint (measured on 8 x 512 x 1024 x 96: bn_apply 0.632 -> 0.603 ms, bn_bwd_apply 1.30 -> 1.16-1.22 ms).
 #define EW_UNROLL 8
 static int ew_blocks(int64_t P, int CQ) {
     int g = CQ, r = 256;   // gcd(CQ, 256)
@@ -153,8 +155,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         for (int u = 0; u < EW_UNROLL; ++u) {
             const int64_t q = p + u * pstep;
             const bool ok = q < P;
-            v[u] = *reinterpret_cast<const f32x4*>(y + (ok ? q : p) * y_cs + c);
-            if (residual) r[u] = *reinterpret_cast<const f32x4*>(residual + (ok ? q : p) * res_cs + c);
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + (ok ? q : p) * y_cs + c));
+            if (residual) r[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(residual + (ok ? q : p) * res_cs + c));
         }
 #pragma unroll
         for (int u = 0; u < EW_UNROLL; ++u) {
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = fmaxf(w[j], 0.f);
             }
-            if (q < P) *reinterpret_cast<f32x4*>(out + q * out_cs + c) = w;
+            if (q < P) __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(out + q * out_cs + c));
         }
     }
 }
@@ -233,10 +235,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t q = p + u * R < p1 ? p + u * R : p;
-                g[u] = *reinterpret_cast<const f32x4*>(g_out + q * g_cs + c);
+                g[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g_out + q * g_cs + c));
                 if (mask_bits) mb[u] = mask_bits[(q * CQ + cq) >> 1] >> (4 * (cq & 1));
-                else if (act == ADH_ACT_RELU && !mask_ss) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
-                yy[u] = *reinterpret_cast<const f32x4*>(y + q * y_cs + c);
+                else if (act == ADH_ACT_RELU && !mask_ss) o[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(out + q * out_cs + c));
+                yy[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + q * y_cs + c));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -366,10 +368,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
         for (int u = 0; u < EW_UNROLL; ++u) {
             const int64_t q = p + u * pstep < P ? p + u * pstep : p;
-            g[u] = *reinterpret_cast<const f32x4*>(g_out + q * g_cs + c);
+            g[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g_out + q * g_cs + c));
             if (mask_bits) mb[u] = mask_bits[(q * CQ + (c >> 2)) >> 1] >> (4 * ((c >> 2) & 1));
-            else if (act == ADH_ACT_RELU && !mask_ss) o[u] = *reinterpret_cast<const f32x4*>(out + q * out_cs + c);
-            if (training) yy[u] = *reinterpret_cast<const f32x4*>(y + q * y_cs + c);
+            else if (act == ADH_ACT_RELU && !mask_ss) o[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(out + q * out_cs + c));
+            if (training) yy[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + q * y_cs + c));
         }
 #pragma unroll
         for (int u = 0; u < EW_UNROLL; ++u) {
@@ -386,11 +388,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                         gg[j] = ov > 0.f ? gg[j] : 0.f;
                     }
                 }
-                if (g_res) *reinterpret_cast<f32x4*>(g_res + q * gres_cs + c) = gg;
+                if (g_res) __builtin_nontemporal_store(gg, reinterpret_cast<f32x4*>(g_res + q * gres_cs + c));
                 f32x4 r;
                 if (training) r = k0 * (gg - mg - (yy[u] - mu) * kx);
                 else r = k0 * gg;
-                *reinterpret_cast<f32x4*>(g_y + q * gy_cs + c) = r;
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(g_y + q * gy_cs + c));
             }
         }
     }

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void cbam_pool_partial_kernel(const float* __r
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int q = p + u * R < p1 ? p + u * R : p;
-                v[u] = *reinterpret_cast<const f32x4*>(xn + (size_t)q * x_cs + c);
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xn + (size_t)q * x_cs + c));
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const float* __
         float s = 0.f, m = -INFINITY;
         int mi = 0x7fffffff;
         for (int q = sub; q < CQ; q += 8) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + q * 4) *
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + q * 4)) *
                             *reinterpret_cast<const f32x4*>(can + q * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -297,13 +297,13 @@ __global__ __launch_bounds__(256) void cbam_scale_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t q = p + u * pstep < HW ? p + u * pstep : p;
-            v[u] = *reinterpret_cast<const f32x4*>(xn + q * x_cs + c);
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xn + q * x_cs + c));
             sv[u] = san[q];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t q = p + u * pstep;
-            if (q < HW) *reinterpret_cast<f32x4*>(on + q * out_cs + c) = v[u] * cav * sv[u];
+            if (q < HW) __builtin_nontemporal_store(v[u] * cav * sv[u], reinterpret_cast<f32x4*>(on + q * out_cs + c));
         }
     }
 }
@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256) void cbam_bwd_a_kernel(const float* __restrict
     for (int p = blockIdx.x * 32 + (threadIdx.x >> 3); p < HW; p += gridDim.x * 32) {
         float s = 0.f;
         for (int q = sub; q < CQ; q += 8) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + q * 4) *
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + q * 4)) *
                             *reinterpret_cast<const f32x4*>(can + q * 4) *
-                            *reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + q * 4);
+                            __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + q * 4));
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }
 #pragma unroll
@@ -486,8 +486,8 @@ __global__ __launch_bounds__(256) void cbam_bwd_c_kernel(const float* __restrict
         const int p1 = adh_min_i(p0 + POOL_PPB, HW);
         for (int p = p0 + prow; p < p1; p += R) {
             const size_t pp = (size_t)n * HW + p;
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + c);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + c);
+            const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + c));
+            const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xn + (size_t)p * x_cs + c));
             const f32x4 gx1 = cbam_gx1(gv, sa[pp], gsmap[pp * 2 + 0] * invC, gsmap[pp * 2 + 1], cidx[pp], c);
             s += gx1 * xv;
         }
@@ -632,14 +632,14 @@ __global__ __launch_bounds__(256) void cbam_bwd_e_kernel(const float* __restrict
         const int p = (int)(idx / CQ);
         const int c = (int)(idx - (int64_t)p * CQ) * 4;
         const size_t pp = (size_t)n * HW + p;
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + c);
+        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + c));
         f32x4 r = cbam_gx1(gv, sa[pp], gsmap[pp * 2 + 0] * invC, gsmap[pp * 2 + 1], cidx[pp], c);
         r = r * *reinterpret_cast<const f32x4*>(ca + (size_t)n * C + c) +
             *reinterpret_cast<const f32x4*>(gpool + ((size_t)n * 2 + 0) * C + c) * invHW;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (amax_idx[(size_t)n * C + c + j] == p) r[j] += gpool[((size_t)n * 2 + 1) * C + c + j];
-        *reinterpret_cast<f32x4*>(gxn + (size_t)p * gx_cs + c) = r;
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(gxn + (size_t)p * gx_cs + c));
     }
 }
 
