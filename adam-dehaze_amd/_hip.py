@@ -91,7 +91,7 @@ _SIGNATURES = {
     "adh_conv_wgrad_groups": [PD],
     "adh_wgrad_reduce": [vp, vp, i32, i32, i32, PL, vp, i32],
     "adh_wgrad_reduce_packed": [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32],
-    "adh_bn_finalize": [vp, vp, i32, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp],
+    "adh_bn_finalize": [vp, vp, i32, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp],
     "adh_bn_fold_eval": [vp, i32, vp, vp, vp, vp, f32, vp, vp, vp],
     "adh_bn_eval_bwd_vectors": [vp, i32, i32, vp, vp, vp, vp],
     "adh_bn_apply": [vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, i64, i32, vp],

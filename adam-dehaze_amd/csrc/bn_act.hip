@@ -12,7 +12,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float momentum,
                                                            float* running_mean, float* running_var, float* scale,
-                                                           float* shift, float* save_mean, float* save_invstd) {
+                                                           float* shift, float* save_mean, float* save_invstd, int64_t* num_batches_tracked) {
     // 32 channels x 32 row slices per block; each thread keeps 4 independent fp64 chains in flight
     __shared__ double red[2][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -64,16 +64,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
+        if (num_batches_tracked && c == 0) *num_batches_tracked += 1;     // BatchNorm2d's counter (one writer)
     }
 }
 
 extern "C" int adh_bn_finalize(void* stream, const float* partials, int nblk, int NcP, int C, double count,
                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                               float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd) {
+                               float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                               int64_t* num_batches_tracked) {
     if (!partials || !scale || !shift || nblk < 1 || C < 1 || NcP < C || count <= 0) return ADH_E_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(adh_ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)stream, partials, nblk,
                        NcP, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean,
-                       save_invstd);
+                       save_invstd, num_batches_tracked);
     return adh_check_launch();
 }
 

@@ -28,6 +28,9 @@
 // Epilogue: accumulators -> LDS M[freq][tile][co] (one 32-channel tile at a time), all threads apply A^T M A
 // and the fused epilogue.
 #include "common.h"
+#ifndef W_STORE_AUX
+#define W_STORE_AUX 0   // cache policy of the epilogue stores (buffer instruction aux bits; 2 = nt)
+#endif
 #ifndef W3_DBG
 #define W3_DBG 0   // dev builds of conv_wino32_kernel: 1 = skip the input transform, 2 = skip the contraction, 4 = skip the epilogue, 8 = no staging inside the loop
 #endif
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
                     v += rres[i * 3 + jj];
                     v = {fmaxf(v[0], act_lo), fmaxf(v[1], act_lo), fmaxf(v[2], act_lo), fmaxf(v[3], act_lo)};
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, o_vj | rowpen[i] | colpen[jj],
-                                                           i * o_row + jj * o_px, 0);
+                                                           i * o_row + jj * o_px, W_STORE_AUX);
                     // gfx950 128-bit buffer-store data hazard (conv_wino43.hip, W4_STORE_NOPS): the asm reads the data
                     // registers, so they stay untouched until the wait states behind the store have passed
                     asm volatile("s_nop 1" : "+v"(v)::"memory");

@@ -597,9 +597,7 @@ class Engine:
             NcP = _round_up(Cout, 32)
             H.call("adh_bn_finalize", stats.data_ptr(), nblk, NcP, Cout, float(P), bn.weight.data_ptr(),
                    bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), H.ptr(bn.num_batches_tracked))
             # residual + ReLU (ResidualBlock tail): the backward ReLU mask cannot be recomputed from y alone; keep it as one
             # bit per element (1/32 of `out`) written by this pass instead of reading `out` twice in the backward pass
             mbits = None

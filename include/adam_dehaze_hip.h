@@ -190,7 +190,8 @@ int adh_wgrad_reduce_packed(void* stream, const float* slab, int nsplit, int NcP
 int adh_bn_finalize(void* stream, const float* partials, int nblk, int NcP, int C, double count,
                     const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var,
-                    float* scale, float* shift, float* save_mean, float* save_invstd);
+                    float* scale, float* shift, float* save_mean, float* save_invstd,
+                    int64_t* num_batches_tracked /* optional: BatchNorm2d's int64 counter, incremented by 1 */);
 /* eval mode: scale/shift from running statistics */
 int adh_bn_fold_eval(void* stream, int C, const float* gamma, const float* beta,
                      const float* running_mean, const float* running_var, float eps,
