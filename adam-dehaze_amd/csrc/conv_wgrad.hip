@@ -447,10 +447,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
             const float sg = wave == 1 ? 1.f : -1.f;
             const int rP = wave == 3 ? 1 : 0;
             const float be = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
-            const float* xa = smem + cur * BUF + (rA * WR_HP + 2 * h) * 32 + l31;
-            const float* xb = smem + cur * BUF + (rB * WR_HP + 2 * h) * 32 + l31;
-            const float* gp = smem + cur * BUF + XF + (rP * 32 + 2 * h) * 32 + l31;
-            const float* gq = smem + cur * BUF + XF + (32 + 2 * h) * 32 + l31;
+            // volatile: one ds_read_b32 per element with a 16-bit immediate offset from ONE base register per image, instead
+            // of ds_read2_b32 pairs whose 8-bit offsets force a base update (v_add_u32) every other step -- 56 VALU per tile
+            // that came straight out of the MFMA time; 1.5 LDS reads per MFMA are free
+            typedef const volatile __attribute__((address_space(3))) float* lds_vf;
+            lds_vf xa = (lds_vf)(smem + cur * BUF + (rA * WR_HP + 2 * h) * 32 + l31);
+            lds_vf xb = (lds_vf)(smem + cur * BUF + (rB * WR_HP + 2 * h) * 32 + l31);
+            lds_vf gp = (lds_vf)(smem + cur * BUF + XF + (rP * 32 + 2 * h) * 32 + l31);
+            lds_vf gq = (lds_vf)(smem + cur * BUF + XF + (32 + 2 * h) * 32 + l31);
             // Packed arithmetic: adjacent tile columns sit in register pairs (ds_read2_b32, second offset + one pixel), so
             // every transform step is one v_pk_* on two columns:
             //   (r0, r1), (r2, r3) = va + sg * vb                                  2 x v_pk_fma
