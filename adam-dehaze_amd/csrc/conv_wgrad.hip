@@ -315,16 +315,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const bool g_partial = co0 + 32 * TN > d.Cout;   // this group's last n-tile has channels beyond Cout
 
-    // this wave's halo pieces: piece j = wave + 4u covers halo row j/5, pixels 8*(j%5) .. +7 (wave-uniform scalars)
-    int prow[8], pcb[8], poff[8], pdst[8];   // PU <= 8 (sized literally: a dependent bound breaks hipcc's host pass)
-#pragma unroll
-    for (int u = 0; u < PU; ++u) {
-        const int j = wave + 4 * u;
-        prow[u] = j / 5;
-        pcb[u] = j - prow[u] * 5;
-        poff[u] = prow[u] * xrs + pcb[u] * 8 * xcs;
-        pdst[u] = (prow[u] * WR_HP + pcb[u] * 8) * 32;
-    }
+    // this wave's halo pieces: piece j = wave + 4u covers halo row j/5, pixels 8*(j%5) .. +7.  The wave-uniform row /
+    // column / offsets of a piece are recomputed with a few scalar instructions where they are used: kept in 32 SGPRs
+    // they were spilled to VGPR lanes and came back as ~40-80 v_readlane per tile -- vector instructions inside an
+    // MFMA-bound loop, where scalar ones are free
+    auto piece_row = [&](int u) { return ((wave + 4 * u) * 205) >> 10; };                    // (wave + 4u) / 5, j < 64
+    auto piece_cb = [&](int u) { return (wave + 4 * u) - 5 * piece_row(u); };
     const int npieces = (NP - wave + 3) / 4;
     const bool tail_ok = (lane >> 3) < NC - 32;   // lanes of a right-most piece that hold used pixels
 
@@ -344,11 +340,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 if (u < npieces) {
-                    float* dst = xs + pdst[u];
-                    if (pcb[u] == 4) {
-                        if (tail_ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, so + poff[u], 0, 0);
+                    const int pr = piece_row(u), pc = piece_cb(u);
+                    float* dst = xs + (pr * WR_HP + pc * 8) * 32;
+                    const int po = so + pr * xrs + pc * 8 * xcs;
+                    if (pc == 4) {
+                        if (tail_ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, po, 0, 0);
                     } else {
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, so + poff[u], 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, po, 0, 0);
                     }
                 }
             }
@@ -356,12 +354,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 if (u < npieces) {
-                    float* dst = xs + pdst[u];
-                    const int iy = iy0 + prow[u] * g.xps;
-                    const int c = pcb[u] * 8 + (lane >> 3);
+                    const int pr = piece_row(u), pc = piece_cb(u);
+                    float* dst = xs + (pr * WR_HP + pc * 8) * 32;
+                    const int po = so + pr * xrs + pc * 8 * xcs;
+                    const int iy = iy0 + pr * g.xps;
+                    const int c = pc * 8 + (lane >> 3);
                     const int ix = ix0 + c * g.xps;
                     const bool lane_ok = iy >= 0 && iy < d.IH && c < NC && ix >= 0 && ix < d.IW;
-                    if (lane_ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, so + poff[u], 0, 0);
+                    if (lane_ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, xv, po, 0, 0);
                     if (!lane_ok && c < NC) *reinterpret_cast<f32x4*>(dst + lane * 4) = zero4;
                 }
             }
