@@ -53,6 +53,15 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
+// a - b on float4 as two v_pk_fma_f32 (b * (-1) + a, exact: one rounding) instead of the four v_sub_f32 hipcc emits for a
+// vector subtraction; `m1` is -1.0f held in an SGPR the compiler cannot see through (adh_opaque(-1.f)), otherwise it folds
+// the product back into a subtraction.  Matters where VALU instructions come out of fp32 MFMA time.
+__device__ __forceinline__ float adh_opaque(float v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ f32x4 adh_pksub(const f32x4& a, const f32x4& b, float m1) { return m1 * b + a; }
+
 // conv_rows.hip: direct forward kernel for the 2x2 / 3x3-tap gather forms (0 blocks / ADH_E_UNSUPPORTED when `d`
 // is not one of its shapes; conv_igemm.hip then takes the launch)
 int adh_rows_fwd_num_blocks(const adh_conv_desc* d);

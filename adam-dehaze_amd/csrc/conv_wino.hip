@@ -651,6 +651,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     for (int i = 0; i < 4; ++i)
         colb3[i] = (tcol < 15 ? (3 * wave + i) * W3_RAW_PITCH + (tcol + 1) * 16 : W3_RAW_ROWS * W3_RAW_PITCH + (3 * wave + i) * 16) + cq_l * 4;
     const int vslot_t = tile_t * 16 + ((cq_l ^ ((tile_t >> 1) & 3)) * 4);
+    const float m1 = adh_opaque(-1.f);
     auto transform = [&](int buf) {
         // frequency row by frequency row (row a of B^T d needs two patch rows): 8 patch reads per row instead of 16 in
         // total, but only ~50 live registers -- this kernel has none to spare next to 8*NT accumulator tiles
@@ -664,12 +665,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
             for (int b = 0; b < 4; ++b) {
                 const f32x4 dA = *reinterpret_cast<const f32x4*>(b < 3 ? raw + colb[b] + rA * W3_RAW_PITCH : raw + colb3[rA]);
                 const f32x4 dB = *reinterpret_cast<const f32x4*>(b < 3 ? raw + colb[b] + rB * W3_RAW_PITCH : raw + colb3[rB]);
-                t[b] = a == 1 ? dA + dB : dA - dB;
+                t[b] = a == 1 ? dA + dB : adh_pksub(dA, dB, m1);
             }
-            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 0) * 1024) = t[0] - t[2];
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 0) * 1024) = adh_pksub(t[0], t[2], m1);
             *reinterpret_cast<f32x4*>(Vb + (a * 4 + 1) * 1024) = t[1] + t[2];
-            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 2) * 1024) = t[2] - t[1];
-            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 3) * 1024) = t[1] - t[3];
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 2) * 1024) = adh_pksub(t[2], t[1], m1);
+            *reinterpret_cast<f32x4*>(Vb + (a * 4 + 3) * 1024) = adh_pksub(t[1], t[3], m1);
         }
     };
 
@@ -848,14 +849,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
                 f32x4 m[4];
 #pragma unroll
                 for (int a2 = 0; a2 < 4; ++a2) m[a2] = *reinterpret_cast<const f32x4*>(mp + (a2 * 4 + b2) * (W2_TILES * 32));
-                const f32x4 hs = 0.5f * (m[1] + m[2]), hd = 0.5f * (m[1] - m[2]);
+                const f32x4 hs = 0.5f * (m[1] + m[2]), hd = 0.5f * adh_pksub(m[1], m[2], m1);
                 u[0][b2] = m[0] + hs;
                 u[1][b2] = hd;
                 u[2][b2] = hs + m[3];
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const f32x4 hs = 0.5f * (u[i][1] + u[i][2]), hd = 0.5f * (u[i][1] - u[i][2]);
+                const f32x4 hs = 0.5f * (u[i][1] + u[i][2]), hd = 0.5f * adh_pksub(u[i][1], u[i][2], m1);
                 const f32x4 y[3] = {u[i][0] + hs, hd, hs + u[i][3]};
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) {

@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const unsigned r_vbase = (unsigned)((ey0 * d.OW + ex0) * r_px + (co0 + eq * 4) * 4);
     const unsigned m_wbase = (unsigned)(((wave * 9) * W4_TILES + h) * 32 + l31) * 4u;   // byte address of M[9 wave][h][l31]
     const float* const mp = M + etp * 32 + eq * 4;
+    const float m1 = adh_opaque(-1.f);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
                 f32x4 m[6];
 #pragma unroll
                 for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(mp + (a * 6 + b) * (W4_TILES * 32));
-                const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                const f32x4 s12 = m[1] + m[2], d12 = adh_pksub(m[1], m[2], m1), s34 = m[3] + m[4], d34 = adh_pksub(m[3], m[4], m1);
                 if (half == 0) {   // rows of A^T: [1 1 1 1 1 0], [0 a -a b -b 0], [0 a^2 a^2 b^2 b^2 0], [0 a^3 -a^3 b^3 -b^3 1]
                     u[0][b] = m[0] + s12 + s34;
                     u[1][b] = W4_A * d12 + W4_B * d34;
@@ -422,8 +423,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
-                const f32x4 s12 = u[ii][1] + u[ii][2], d12 = u[ii][1] - u[ii][2], s34 = u[ii][3] + u[ii][4],
-                            d34 = u[ii][3] - u[ii][4];
+                const f32x4 s12 = u[ii][1] + u[ii][2], d12 = adh_pksub(u[ii][1], u[ii][2], m1), s34 = u[ii][3] + u[ii][4],
+                            d34 = adh_pksub(u[ii][3], u[ii][4], m1);
                 const f32x4 y[4] = {u[ii][0] + s12 + s34, W4_A * d12 + W4_B * d34, W4_A2 * s12 + W4_B2 * s34,
                                     W4_A3 * d12 + W4_B3 * d34 + u[ii][5]};
 #pragma unroll
