@@ -79,6 +79,18 @@ def main():
     elif args.mode == "train_dehazing":
         for level in ("low", "medium", "high"):   # train_dehazing.py:216-232
             T.train_dehazing_model(config, level, epochs=args.epochs or 30, resume=args.resume)
+    elif args.mode == "train_all":
+        # main.py:121-139 of the reference: classifier -> dehazing branches -> joint -> evaluation.  Step 1 (stand-alone
+        # classifier training) is outside this build's scope: the joint step fine-tunes the classifier
+        # from whatever checkpoint `classifier.checkpoint_dir` holds, exactly as train_joint.py:18-27 does when it is missing
+        print("\n===== Step 1: fog-intensity classifier training is outside this build's scope: skipped =====")
+        print("\n===== Step 2: Training Dehazing Models =====")
+        for level in ("low", "medium", "high"):
+            T.train_dehazing_model(config, level, epochs=args.epochs or 30, resume=args.resume)
+        print("\n===== Step 3: Training Joint Model =====")
+        T.train_joint_model(config, epochs=args.epochs, resume=args.resume)
+        print("\n===== Step 4: Evaluation (image quality; the detection half needs torchvision detection weights) =====")
+        T.evaluate_joint_model(config)
     elif args.mode == "evaluate":
         # evaluate.py:464-540 runs image-quality evaluation of the joint model, then object detection on dehazed frames;
         # the detector stage needs torchvision detection weights that are not in this image
