@@ -43,12 +43,29 @@
 #define W4_VF (36 * W4_TILES * W4_KC)              // floats of V (73,728 B)
 #define W4_SLOTS 612                               // pixel slots of the raw halo: 18 rows x 34 columns
 #define W4_ROWSLOTS 34
-#define W4_RAWF (40 * 256)                         // floats per raw buffer: 40 DMA pieces of 16 slots (640 >= 612 slots)
-#define W4_TAB (W4_VF + 2 * W4_RAWF)               // float offset of the slot tables
-#define W4_RED (W4_TAB + 2 * 640)                  // statistics scratch
+#define W4_RAWF (40 * 256)                         // floats of the raw buffer: 40 DMA pieces of 16 slots (640 >= 612 slots)
+#define W4_TAB (W4_VF + W4_RAWF)                   // float offset of the lane offset table [640 slots][4 quads]
+#define W4_TABOK (W4_TAB + 4 * 640)                // [640 slots][4 quads] slot-inside-image flags (same indexing: one lane pointer)
+#define W4_MF (36 * W4_TILES * 32)                 // floats of the epilogue's M (147,456 B: spans V, raw and the tables)
+#define W4_RED W4_MF                               // statistics scratch (behind M)
 #define W4_LDS_BYTES ((W4_RED + 2 * 8 * 32) * 4)
+static_assert(W4_TABOK + 4 * 640 <= W4_MF, "tables must end before the statistics scratch");
+#ifndef W4_P2
+#define W4_P2 0                                    // DMA pieces (of 10 per wave and chunk) issued during transform pass 2 ...
+#endif
+#define W4_PIECE_G0 2                              // ... the others one per contraction group from group W4_PIECE_G0 on
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr4;
+
+#ifdef W4_PROF   // dev build (tools/prof_wino43.sh): per-workgroup s_memtime stamps and the CU each workgroup ran on
+__device__ unsigned long long w4_prof_buf[16384 * 32];
+#define W4_STAMP(i) do { if (tid == 0 && bid < 16384) w4_prof_buf[bid * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int adh_w4_prof_read(void* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(w4_prof_buf), sizeof(w4_prof_buf)) == hipSuccess ? 0 : -1;
+}
+#else
+#define W4_STAMP(i) do {} while (0)
+#endif
 
 struct Wino43Geom {
     int tiles_x, tiles_y;        // 32-col x 16-row regions
@@ -73,15 +90,25 @@ __device__ __forceinline__ void w4_mfma(f32x16& c, float a, float b) {
     if constexpr (AGPR) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-// one group: local frequency FI, NT output-channel tiles, 4 k-steps
-template <int NT, int FI, int KK, int J>
+// one group: local frequency FI, NT output-channel tiles, k-steps KK .. KEND-1 (a whole group: 0 .. 3)
+template <int NT, int FI, int KK, int J, int KEND = 4>
 __device__ __forceinline__ void w4_group(f32x16 (&acc)[9 * NT], const f32x4& a, const f32x4 (&b)[NT]) {
-    if constexpr (KK < 4) {
+    if constexpr (KK < KEND) {
         w4_mfma<w4_in_agpr<NT, FI, J>()>(acc[FI * NT + J], a[KK], b[J][KK]);
-        if constexpr (J + 1 < NT) w4_group<NT, FI, KK, J + 1>(acc, a, b);
-        else w4_group<NT, FI, KK + 1, 0>(acc, a, b);
+        if constexpr (J + 1 < NT) w4_group<NT, FI, KK, J + 1, KEND>(acc, a, b);
+        else w4_group<NT, FI, KK + 1, 0, KEND>(acc, a, b);
     }
 }
+// does contraction group G carry a staging piece?  (dev build W4_DBG & 8: no staging inside the loop)
+constexpr int w4_piece(int G) { return (!(W4_DBG & 8) && G >= W4_PIECE_G0 && G < W4_PIECE_G0 + 10 - W4_P2) ? 1 : 0; }
+constexpr int w4_p2_pieces() { return (W4_DBG & 8) ? 0 : W4_P2; }
+struct W4Stage {                 // what a contraction group needs to issue one LDS-DMA piece of the NEXT chunk's raw halo
+    __amdgpu_buffer_rsrc_t rsrc; // the image
+    const int* tab_lane;         // this lane's entry of the offset table; piece u at [256 u]
+    float* lds;
+    int lds_wave;                // byte offset of this wave's piece 0 in LDS (wave-uniform)
+    int cb;                      // byte offset of the chunk's first channel (wave-uniform)
+};
 template <int NT>
 __device__ __forceinline__ void w4_load_b(f32x4 (&b)[NT], unsigned voff, const float* sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(voff), "s"(sbase) : "memory");
@@ -148,7 +175,7 @@ __device__ __forceinline__ void w4_store_m(const f32x16 (&acc)[9 * NT], unsigned
 template <int NT, int GI>
 __device__ __forceinline__ void w4_chunk(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], f32x4 (&bv)[3][NT], const float* vlane,
                                          const float* vlane1, unsigned b_voff, const float* b_chunk, const float* b_next, int64_t b_fstride,
-                                         int b_kq2) {
+                                         int b_kq2, const W4Stage& st) {
     if constexpr (GI < 18) {
         // operands two groups ahead (weights) / one group ahead (V)
         constexpr int G2 = GI + 2;
@@ -158,18 +185,33 @@ __device__ __forceinline__ void w4_chunk(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], 
             constexpr int G1 = GI + 1;
             av[G1 & 1] = *reinterpret_cast<const f32x4*>((G1 / 9 ? vlane1 : vlane) + (G1 % 9) * (W4_TILES * W4_KC));
         }
-        w4_wait_b<2 * NT, NT>(bv[GI % 3]);
-        w4_group<NT, GI % 9, 0, 0>(acc, av[GI & 1], bv[GI % 3]);
-        w4_chunk<NT, GI + 1>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, b_kq2);
+        // newer than this group's weights: the weights of the next two groups and the pieces of the previous two
+        if constexpr (w4_piece(GI)) {
+            constexpr int u = W4_P2 + GI - W4_PIECE_G0;
+            const int vo = st.tab_lane[256 * u];
+            w4_wait_b<2 * NT + w4_piece(GI - 2) + w4_piece(GI - 1), NT>(bv[GI % 3]);
+            w4_group<NT, GI % 9, 0, 0, 1>(acc, av[GI & 1], bv[GI % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            // one piece of the next chunk's halo, behind the first k-step: the MFMA pipe is busy for NT * 64 cycles and the
+            // raw buffer has no reader between the transform of this chunk and the end of its contraction
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(st.lds) + st.lds_wave + u * 4096),
+                                                     16, vo, st.cb, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            w4_group<NT, GI % 9, 1, 0>(acc, av[GI & 1], bv[GI % 3]);
+        } else {
+            w4_wait_b<2 * NT + w4_piece(GI - 2) + w4_piece(GI - 1), NT>(bv[GI % 3]);
+            w4_group<NT, GI % 9, 0, 0>(acc, av[GI & 1], bv[GI % 3]);
+        }
+        w4_chunk<NT, GI + 1>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, b_kq2, st);
     }
 }
 
 template <int NT>
 __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc d, const Wino43Geom g) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // V | raw[2] | slot tables | red ; M aliases V + raw
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // V | raw | slot tables | .. | red ; M aliases V .. red
     float* const rawbase = lds + W4_VF;
-    int* const tab_off = reinterpret_cast<int*>(lds + W4_TAB);          // [640] source byte offset of slot s (clamped)
-    int* const tab_ok = tab_off + 640;                                   // [640] 1 if slot s lies inside the image
+    int* const tab_off = reinterpret_cast<int*>(lds + W4_TAB);          // [640][4] source byte offset of (slot s, channel quad q) (clamped)
+    int* const tab_ok = reinterpret_cast<int*>(lds + W4_TABOK);         // [640][4] 1 if slot s lies inside the image
     float* const red = lds + W4_RED;
 
     const int tid = threadIdx.x;
@@ -179,6 +221,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const int h = lane >> 5;
 
     const int bid = blockIdx.x;
+    W4_STAMP(0);
+#ifdef W4_PROF
+    if (tid == 0 && bid < 16384) {
+        w4_prof_buf[bid * 32 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+        w4_prof_buf[bid * 32 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+    }
+#endif
     const int q = bid >> 3;
     const int cg = q % g.ncog;
     const int region = (q / g.ncog) * 8 + (bid & 7);
@@ -201,33 +250,40 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         const int idx = rem - (plane == 0 ? 0 : (plane == 1 ? 9 : (plane == 2 ? 18 : 26)));
         const int iy = oy0 - 1 + row, ix = ox0 - 1 + 4 * idx + plane;
         const int iyc = adh_min_i(adh_max_i(iy, 0), d.IH - 1), ixc = adh_min_i(adh_max_i(ix, 0), d.IW - 1);
-        tab_off[s] = (iyc * d.IW + ixc) * xcs;
-        tab_ok[s] = (s < W4_SLOTS && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) ? 1 : 0;
+        const int off = (iyc * d.IW + ixc) * xcs;
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<i32x4*>(tab_off + 4 * s) = i32x4{off, off + 16, off + 32, off + 48};
+        const int ok = (s < W4_SLOTS && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) ? 1 : 0;
+        *reinterpret_cast<i32x4*>(tab_ok + 4 * s) = i32x4{ok, ok, ok, ok};
     }
     const float* in_n = d.in + (int64_t)n * d.IH * d.IW * d.in_cstride;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, 0x7fffffff, 0x00020000);
-    const int cq_l = lane & 3, px_l = lane >> 2;
-    // 40 pieces per chunk, 10 per wave: piece k = 4u + wave covers slots 16k..16k+15 (slots >= 612 repeat slot 611)
-    const int* const tab_lane = tab_off + 16 * wave + px_l;
-    auto stage_raw = [&](int c, int buf) {
-        const int cb = c * (W4_KC * 4);
-        const int lo = __builtin_amdgcn_readfirstlane((W4_VF + buf * W4_RAWF + wave * 256) * 4);
+    const int cq_l = lane & 3;
+    // 40 pieces per chunk, 10 per wave: piece k = 4u + wave covers slots 16k..16k+15 (slots >= 612 repeat slot 611); lane l of
+    // piece k loads (slot 16k + l / 4, quad l % 4): its table entry is tab_off[64 k + l], i.e. one contiguous read per piece
+    W4Stage st;
+    st.rsrc = xr;
+    st.tab_lane = tab_off + 64 * wave + lane;
+    st.lds = lds;
+    st.lds_wave = __builtin_amdgcn_readfirstlane((W4_VF + wave * 256) * 4);
+    st.cb = 0;
+    auto stage_first = [&]() {   // chunk 0 (prologue); the later chunks arrive piece by piece inside the contraction
         int vo[10];   // all table reads first: one LDS round trip instead of ten
 #pragma unroll
-        for (int u = 0; u < 10; ++u) vo[u] = tab_lane[64 * u];
+        for (int u = 0; u < 10; ++u) vo[u] = st.tab_lane[256 * u];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 10; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + lo + u * 4096), 16,
-                                                     vo[u] + cq_l * 16, cb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + u * 4096), 16,
+                                                     vo[u], 0, 0, 0);
     };
-    auto fix_raw = [&](int buf) {
+    auto fix_raw = [&]() {
         if (interior) return;
-        float* raw = rawbase + buf * W4_RAWF + wave * 256 + lane * 4;
+        float* raw = rawbase + wave * 256 + lane * 4;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 10; ++u)
-            if (!tab_lane[640 + 64 * u]) *reinterpret_cast<f32x4*>(raw + u * 1024) = z;
+            if (!st.tab_lane[4 * 640 + 256 * u]) *reinterpret_cast<f32x4*>(raw + u * 1024) = z;
     };
 
     // ------------------------------------------------------------------ input transform (two 1-D passes through LDS)
@@ -237,21 +293,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const int vslot_t = tile_t * 16 + ((cq_l ^ ((tile_t >> 1) & 3)) * 4);      // swizzled quad slot inside V[f][tile]
     // patch pixel (row i, column c) of this thread's tile sits in raw row 4*trow + i, plane c & 3, index tcol + (c >> 2);
     // slot offset of column c = 2k + csel inside a row: {0, 18, 1} (csel 0: planes 0, 2, 0) / {9, 26, 10} (csel 1)
+    // -> two lane pointers (k = 0 and, one slot further, k = 2; k = 1), the patch row is an instruction immediate
     const int rbase_t = ((4 * trow) * W4_ROWSLOTS + tcol) * 16 + cq_l * 4;
-    auto raw_off = [&](int i, int k) {
-        const int cs = k == 0 ? (csel ? 9 : 0) : (k == 1 ? (csel ? 26 : 18) : (csel ? 10 : 1));
-        return rbase_t + (i * W4_ROWSLOTS + cs) * 16;
-    };
+    const int raw_k0 = (W4_VF + rbase_t) / 4 + (csel ? 9 : 0) * 4;      // float4 indices into lds[] (an opaque *pointer* would lose the LDS
+    const int raw_k1 = (W4_VF + rbase_t) / 4 + (csel ? 26 : 18) * 4;    // address space: flat loads; an opaque float index the alignment: b32 reads)
     const W4Neg negc = w4_neg_constants();
-    auto transform = [&](int buf) {
-        const float* raw = rawbase + buf * W4_RAWF;
+    auto transform = [&]() {
         // pass 1: T[a][c] = sum_i B^T[a][i] d[i][c] for this thread's three columns c = csel, 2 + csel, 4 + csel
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int c = 2 * k + csel;
             f32x4 dd[6];
+            int rp = k == 1 ? raw_k1 : raw_k0 + (k == 2 ? 4 : 0);
+            asm volatile("" : "+v"(rp));   // (keeps the six row addresses from being hoisted out of the chunk loop into six registers)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) dd[i] = *reinterpret_cast<const f32x4*>(raw + raw_off(i, k));
+            for (int i = 0; i < 6; ++i) dd[i] = reinterpret_cast<const f32x4*>(lds)[rp + i * (W4_ROWSLOTS * 4)];
             w4_bt_store(dd, lds + c * (W4_TILES * W4_KC) + vslot_t, 6 * W4_TILES * W4_KC, negc);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -262,9 +318,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         for (int k = 0; k < 3; ++k) {
             const int a = 2 * k + csel;
             f32x4 tt[6];
+            // pieces k, k + 3, .. of the next chunk's halo (the raw buffer's last reader was pass 1): table entries first
+            int vo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + 3 * e < w4_p2_pieces()) vo[e] = st.tab_lane[256 * (k + 3 * e)];
 #pragma unroll
             for (int c = 0; c < 6; ++c) tt[c] = *reinterpret_cast<const f32x4*>(lds + (a * 6 + c) * (W4_TILES * W4_KC) + vslot_t);
             w4_bt_store(tt, lds + (a * 6) * (W4_TILES * W4_KC) + vslot_t, W4_TILES * W4_KC, negc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + 3 * e < w4_p2_pieces())
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + (k + 3 * e) * 4096),
+                                                             16, vo[e], st.cb, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -287,51 +353,59 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     __syncthreads();   // slot tables
     w4_load_b<NT>(bv[0], b_voff, b_wave);
     w4_load_b<NT>(bv[1], b_voff, b_wave + b_fstride);
-    stage_raw(0, 0);
+    stage_first();
 #pragma unroll
     for (int t = 0; t < 9 * NT; ++t)   // (zeroing 9*NT*16 registers hides under the first DMA round trip)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fix_raw(0);
+    fix_raw();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    W4_STAMP(1);
 #pragma unroll 1
     for (int c = 0; c < g.nchunks; ++c) {
         const bool more = c + 1 < g.nchunks;
         const int cn = more ? c + 1 : c;   // the last chunk re-stages itself (uniform counts)
         // ---- transform raw(c) -> V (every wave is past the previous chunk's contraction: barrier at the loop end)
-        // the next chunk's raw tile goes into the other buffer (its last reader was the transform of chunk c - 1)
-        if (!(W4_DBG & 8)) stage_raw(cn, (c + 1) & 1);
-        if (!(W4_DBG & 1)) transform(c & 1);
+        st.cb = cn * (W4_KC * 4);
+        if (c == 1) W4_STAMP(8);
+        if (c == 1) W4_STAMP(9);
+        if (!(W4_DBG & 1)) transform();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (c == 1) W4_STAMP(10);
         __builtin_amdgcn_s_barrier();
-        // ---- contraction.  In flight: the weights of groups 0 and 1 (older than the 10 DMA pieces)
+        if (c == 1) W4_STAMP(11);
+        // ---- contraction.  In flight: the weights of groups 0 and 1 and, newer, the pieces pass 2 issued.  The raw buffer is
+        // free from pass 2 to the end of the contraction (its only reader is pass 1), so the next chunk's halo lands in it
+        // meanwhile; the weight waits of the later groups retire the pieces in order
         if (!(W4_DBG & 2)) {
-            // groups 0 and 1 see the 10 DMA pieces and two later weight sets as newer operations
             const float* b_chunk = b_wave + (int64_t)(c * 4) * b_kq;
             const float* b_next = b_wave + (int64_t)(cn * 4) * b_kq;
             av[0] = *reinterpret_cast<const f32x4*>(vlane);
             // group 0
             w4_load_b<NT>(bv[2], b_voff, b_chunk + 2 * b_fstride);
             av[1] = *reinterpret_cast<const f32x4*>(vlane + 1 * (W4_TILES * W4_KC));
-            w4_wait_b<2 * NT + ((W4_DBG & 8) ? 0 : 10), NT>(bv[0]);
+            w4_wait_b<2 * NT + w4_p2_pieces(), NT>(bv[0]);
             w4_group<NT, 0, 0, 0>(acc, av[0], bv[0]);
             // group 1
             w4_load_b<NT>(bv[0], b_voff, b_chunk + 3 * b_fstride);
             av[0] = *reinterpret_cast<const f32x4*>(vlane + 2 * (W4_TILES * W4_KC));
-            w4_wait_b<2 * NT + ((W4_DBG & 8) ? 0 : 10), NT>(bv[1]);
+            w4_wait_b<2 * NT + w4_p2_pieces(), NT>(bv[1]);
             w4_group<NT, 1, 0, 0>(acc, av[1], bv[1]);
-            // groups 2..17 (their waits retire the DMA pieces first: in-order return)
-            w4_chunk<NT, 2>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, 2 * b_kq);
+            // groups 2..17
+            w4_chunk<NT, 2>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, 2 * b_kq, st);
         }
-        fix_raw((c + 1) & 1);
+        if (c == 1) W4_STAMP(12);
+        fix_raw();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (c == 1) W4_STAMP(13);
     }
     w4_wait_b<0, NT>(bv[0]);
     w4_wait_b<0, NT>(bv[1]);
+    W4_STAMP(2);
 
     // ---------------------------------------------------------------------- output transform A^T M A + fused epilogue
     // One output-channel tile (32 co) at a time: accumulators -> M[36][32 tile rows][32 co] in LDS (tile t sits in row
@@ -376,12 +450,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+        if (j == 1) W4_STAMP(16);
         __builtin_amdgcn_s_barrier();   // V / raw (first tile) or the previous tile's M fully consumed
+        if (j == 1) W4_STAMP(17);
         if (j == 0) w4_store_m<NT, 0, 0, 0>(acc, m_wbase);
         if (j == 1) w4_store_m<NT, (NT > 1 ? 1 : 0), 0, 0>(acc, m_wbase);
         if (j == 2) w4_store_m<NT, (NT > 2 ? 2 : 0), 0, 0>(acc, m_wbase);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j == 1) W4_STAMP(18);
         __builtin_amdgcn_s_barrier();
+        if (j == 1) W4_STAMP(19);
         const int cq0 = co0 + j * 32 + eq * 4;
         const bool quad_ok = cq0 + 3 < d.Cout;             // Cout % 4 == 0 (wino43_plan): a quad is real or padding
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
@@ -392,6 +470,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            if (j == 1 && half == 1) W4_STAMP(20);
             f32x4 u[2][6];
             f32x4 rres[8];   // the residual of this half's 2 x 4 pixels, in flight during the transform
             if (res_n) {   // workgroup-uniform; the asm keeps it a branch (the zero-initialised alternative is free)
@@ -453,6 +532,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
                 }
             }
         }
+        if (j == 1) W4_STAMP(21);
         if (d.stats) {
             // sum over the 8 tiles of this wave (lane bits 3..5), then over the 4 waves through LDS
 #pragma unroll
@@ -479,6 +559,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             }
         }
     }
+    W4_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
