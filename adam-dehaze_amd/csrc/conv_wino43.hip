@@ -161,12 +161,17 @@ __device__ __forceinline__ void w4_bt_store(f32x4 (&d)[6], float* dst, int strid
 template <int NT, int J, int FI, int R>
 __device__ __forceinline__ void w4_store_m(const f32x16 (&acc)[9 * NT], unsigned addr) {
     if constexpr (FI < 9) {
-        constexpr int off = (FI * W4_TILES + 8 * (R >> 2) + ((R & 3) << 1)) * 128;
+        // registers R and R + 1 sit two tile rows = 256 B apart: one ds_write2st64_b32 (offsets in units of 256 B) moves both
+        constexpr int off = FI * 16 + (R >> 2) * 4 + (R & 3);
         if constexpr (w4_in_agpr<NT, FI, J>())
-            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "a"(acc[FI * NT + J][R]), "n"(off) : "memory");
+            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "a"(acc[FI * NT + J][R]),
+                         "a"(acc[FI * NT + J][R + 1]), "n"(off), "n"(off + 1)
+                         : "memory");
         else
-            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(acc[FI * NT + J][R]), "n"(off) : "memory");
-        if constexpr (R + 1 < 16) w4_store_m<NT, J, FI, R + 1>(acc, addr);
+            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(acc[FI * NT + J][R]),
+                         "v"(acc[FI * NT + J][R + 1]), "n"(off), "n"(off + 1)
+                         : "memory");
+        if constexpr (R + 2 < 16) w4_store_m<NT, J, FI, R + 2>(acc, addr);
         else w4_store_m<NT, J, FI + 1, 0>(acc, addr);
     }
 }
