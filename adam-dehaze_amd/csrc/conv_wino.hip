@@ -84,13 +84,13 @@ __device__ __forceinline__ void w2_store_m(const f32x16 (&acc)[8 * NT], unsigned
 }
 
 // one contraction group: local frequency F, both tile halves, NT output-channel tiles, 4 k-steps
-template <int NT, int F, int KK, int TH, int J>
+template <int NT, int F, int KK, int TH, int J, int KEND = 4>   // k-steps KK .. KEND-1 (a whole group: 0 .. 3)
 __device__ __forceinline__ void w2_group(f32x16 (&acc)[8 * NT], const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
-    if constexpr (KK < 4) {
+    if constexpr (KK < KEND) {
         w2_mfma<w2_in_agpr<NT, F * 2 + TH, J>()>(acc[(F * 2 + TH) * NT + J], a[TH][KK], b[J][KK]);
-        if constexpr (J + 1 < NT) w2_group<NT, F, KK, TH, J + 1>(acc, a, b);
-        else if constexpr (TH == 0) w2_group<NT, F, KK, 1, 0>(acc, a, b);
-        else w2_group<NT, F, KK + 1, 0, 0>(acc, a, b);
+        if constexpr (J + 1 < NT) w2_group<NT, F, KK, TH, J + 1, KEND>(acc, a, b);
+        else if constexpr (TH == 0) w2_group<NT, F, KK, 1, 0, KEND>(acc, a, b);
+        else w2_group<NT, F, KK + 1, 0, 0, KEND>(acc, a, b);
     }
 }
 
@@ -581,19 +581,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, 0x7fffffff, 0x00020000);
     const int cq_l = lane & 3, px_l = lane >> 2;
     // all classes' halo columns are inside the image: no clamping / fixing needed (rows are checked per piece)
-    auto stage_raw = [&](int slab, int buf) {
+    // pieces u0 .. u1-1 of the 10 this wave stages per slab (the whole tile in the prologue, two per contraction group later)
+    const int vfull = 3 * px_l * xcs + cq_l * 16;
+    const int vtail = (px_l < W3_RAW_ROWS ? px_l : 0) * xrs + 48 * xcs + cq_l * 16;
+    struct SlabGeom { int iy0, ix0, cb, so0; bool interior; };   // wave-uniform, computed once per slab
+    auto slab_geom = [&](int slab) {
+        SlabGeom sg;
         const int chunk = slab / g.ncls, c = slab - chunk * g.ncls;
-        const int iy0 = vy0 * g.xps + g.ymin[c], ix0 = vx0 * g.xps + g.xmin[c];
+        sg.iy0 = vy0 * g.xps + g.ymin[c];
+        sg.ix0 = vx0 * g.xps + g.xmin[c];
+        sg.interior = sg.iy0 >= 0 && sg.iy0 + 12 * g.xps < d.IH && sg.ix0 >= 0 && sg.ix0 + 48 * g.xps < d.IW;
+        sg.cb = chunk * 64;
+        sg.so0 = (sg.iy0 * d.IW + sg.ix0) * d.in_cstride * 4 + sg.cb;
+        return sg;
+    };
+    auto stage_raw = [&](const SlabGeom& sg, int buf, int u0, int u1) {
+        const int iy0 = sg.iy0, ix0 = sg.ix0, cb = sg.cb, so0 = sg.so0;
         float* raw = rawbase + buf * W3_RAW_F;
-        const bool interior = iy0 >= 0 && iy0 + 12 * g.xps < d.IH && ix0 >= 0 && ix0 + 48 * g.xps < d.IW;
-        const int cb = chunk * 64;
-        if (interior) {
-            const int so0 = (iy0 * d.IW + ix0) * d.in_cstride * 4 + cb;
-            const int vfull = 3 * px_l * xcs + cq_l * 16;
-            const int vtail = (px_l < W3_RAW_ROWS ? px_l : 0) * xrs + 48 * xcs + cq_l * 16;
+        int wv = wave;
+        asm volatile("" : "+s"(wv));   // the piece geometry is a few SALU per piece; hoisted out of the slab loop it lands in spilled SGPRs, and every reload is a v_readlane in the MFMA stream
+        if (sg.interior) {
 #pragma unroll
-            for (int u = 0; u < 10; ++u) {
-                const int j = 4 * u + wave;
+            for (int u = u0; u < u1; ++u) {
+                const int j = 4 * u + wv;
                 if (j < 39) {
                     const int r = (j * 171) >> 9, p = j - r * 3;       // j / 3
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + r * W3_RAW_PITCH + p * 256), 16, vfull,
@@ -607,8 +617,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
             // clamped per-lane coordinates: every instruction issues with all lanes; fix_raw zeroes the cells that lie
             // outside the image after they have landed
 #pragma unroll
-            for (int u = 0; u < 10; ++u) {
-                const int j = 4 * u + wave;
+            for (int u = u0; u < u1; ++u) {
+                const int j = 4 * u + wv;
                 const bool tail = j >= 39;
                 const int rs = (j * 171) >> 9, p = tail ? 0 : j - rs * 3;      // full pieces: row, plane (wave-uniform)
                 const int r = tail ? (px_l < W3_RAW_ROWS ? px_l : 0) : rs;
@@ -702,11 +712,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     // ------------------------------------------------------------------ prologue
     const int nslabs = g.nchunks * g.ncls;
     w2_load_b<NT>(bv[0], b_voff, b_ptr(0, 0, 0));
-    stage_raw(0, 0);
-    stage_raw(nslabs > 1 ? 1 : 0, 1);
+    stage_raw(slab_geom(0), 0, 0, 10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fix_raw(0, 0);
-    fix_raw(nslabs > 1 ? 1 : 0, 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (!(W3_DBG & 1)) transform(0);
@@ -715,55 +723,64 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
 
 #pragma unroll 1
     for (int s = 0; s < nslabs; ++s) {
-        // raw(s+1) sits in buffer (s+1)&1; raw(s+2) is staged into buffer s&1 (free since transform(s)) from the LAST group
-        // of this slab: vmcnt returns in order, so every weight wait behind the DMA also waits for the DMA -- issued there,
-        // the pieces have the last group, the transform and the next slab's first group (whose weights are already in
-        // flight) to land, instead of two groups
-        const int s2 = s + 2 < nslabs ? s + 2 : s;     // the last two slabs re-issue an earlier tile: uniform counts
-        const int sn = s + 1 < nslabs ? s + 1 : s;
+        // raw(s+1) is staged into buffer (s+1)&1 (whose last reader was the transform of slab s-1) during this slab's
+        // contraction: two pieces behind the first k-step of groups 1..5 -- issued back to back the ten pieces block the
+        // wave's instruction stream for ~1700 cycles (tools/prof_wino43.py), spread out they hide behind the MFMAs.  vmcnt
+        // returns in order: the weight wait of group i allows the next weight set and the pieces of group i-1 to be
+        // outstanding, and the wait of group 7 retires the last pieces.
+        const int sn = s + 1 < nslabs ? s + 1 : s;     // the last slab re-stages itself: uniform counts
+        constexpr int P = (W3_DBG & 8) ? 0 : 2;
+        const SlabGeom sgn = slab_geom(sn);
         if (!(W3_DBG & 2)) {
         load_a(0, 0, av[0]);
         w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 1, 0));
         load_a(1, 0, av[1]);
-        w2_wait_b<NT + ((W3_DBG & 8) ? 0 : 10), NT>(bv[0]);       // (the previous slab's 10 raw pieces may still be in flight)
+        w2_wait_b<NT, NT>(bv[0]);
         w2_group<NT, 0, 0, 0, 0>(acc, av[0], bv[0]);
+
+#define W3_GROUP_WITH_PIECES(F_, CUR, U0)                                             \
+        w2_group<NT, F_, 0, 0, 0, 1>(acc, av[CUR], bv[CUR]);                           \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        if (P) stage_raw(sgn, (s + 1) & 1, U0, U0 + 2);                               \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        w2_group<NT, F_, 1, 0, 0>(acc, av[CUR], bv[CUR]);
 
         w2_load_b<NT>(bv[0], b_voff, b_ptr(s, 2, 0));
         load_a(2, 0, av[0]);
-        w2_wait_b<NT, NT>(bv[1]);            // also retires those raw pieces (in-order return)
-        w2_group<NT, 1, 0, 0, 0>(acc, av[1], bv[1]);
+        w2_wait_b<NT, NT>(bv[1]);
+        W3_GROUP_WITH_PIECES(1, 1, 0)
 
         w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 3, 0));
         load_a(3, 0, av[1]);
-        w2_wait_b<NT, NT>(bv[0]);
-        w2_group<NT, 2, 0, 0, 0>(acc, av[0], bv[0]);
+        w2_wait_b<NT + P, NT>(bv[0]);
+        W3_GROUP_WITH_PIECES(2, 0, 2)
 
         w2_load_b<NT>(bv[0], b_voff, b_ptr(s, 0, 1));
         load_a(0, 1, av[0]);
-        w2_wait_b<NT, NT>(bv[1]);
-        w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
+        w2_wait_b<NT + P, NT>(bv[1]);
+        W3_GROUP_WITH_PIECES(3, 1, 4)
 
         w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 1, 1));
         load_a(1, 1, av[1]);
-        w2_wait_b<NT, NT>(bv[0]);
-        w2_group<NT, 0, 0, 0, 0>(acc, av[0], bv[0]);
+        w2_wait_b<NT + P, NT>(bv[0]);
+        W3_GROUP_WITH_PIECES(0, 0, 6)
 
         w2_load_b<NT>(bv[0], b_voff, b_ptr(s, 2, 1));
         load_a(2, 1, av[0]);
-        w2_wait_b<NT, NT>(bv[1]);
-        w2_group<NT, 1, 0, 0, 0>(acc, av[1], bv[1]);
+        w2_wait_b<NT + P, NT>(bv[1]);
+        W3_GROUP_WITH_PIECES(1, 1, 8)
+#undef W3_GROUP_WITH_PIECES
 
         w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 3, 1));
         load_a(3, 1, av[1]);
-        w2_wait_b<NT, NT>(bv[0]);
+        w2_wait_b<NT + P, NT>(bv[0]);
         w2_group<NT, 2, 0, 0, 0>(acc, av[0], bv[0]);
 
         w2_load_b<NT>(bv[0], b_voff, b_ptr(sn, 0, 0));
-        if (!(W3_DBG & 8)) stage_raw(s2, s & 1);
-        w2_wait_b<NT + ((W3_DBG & 8) ? 0 : 10), NT>(bv[1]);
+        w2_wait_b<NT, NT>(bv[1]);               // everything older than bv[0], the pieces included, has landed
         w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
         }
-        // ---- V is free once every wave is here; raw(s+1) landed during this slab (second wait above)
+        // ---- V is free once every wave is here; raw(s+1) landed during this slab (last wait above)
         fix_raw(sn, (s + 1) & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
