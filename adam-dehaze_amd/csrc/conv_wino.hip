@@ -538,6 +538,16 @@ extern "C" int adh_conv_wino_forward(void* stream, const adh_conv_desc* d) {
 #define W3_RAW_F (W3_RAW_ROWS * W3_RAW_PITCH + 256)  // + tail [16 slots][16 ch]: column 48 of rows 0..12
 #define W3_LDS_BYTES ((W2_VBUF_F + 2 * W3_RAW_F + 2 * 8 * 32) * 4)
 
+#ifdef W3_PROF   // dev build (tools/prof_wino43.sh): per-workgroup s_memtime stamps and the CU each workgroup ran on
+__device__ unsigned long long w3_prof_buf[16384 * 32];
+#define W3_STAMP(i) do { if (tid == 0 && bid < 16384) w3_prof_buf[bid * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int adh_w3_prof_read(void* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(w3_prof_buf), sizeof(w3_prof_buf)) == hipSuccess ? 0 : -1;
+}
+#else
+#define W3_STAMP(i) do {} while (0)
+#endif
+
 struct Wino32Geom {
     int tiles_x, tiles_y;        // 48-col x 12-row regions of virtual pixels
     int nregions;
@@ -562,6 +572,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     const int h = lane >> 5;
 
     const int bid = blockIdx.x;
+    W3_STAMP(0);
+#ifdef W3_PROF
+    if (tid == 0 && bid < 16384) {
+        w3_prof_buf[bid * 32 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+        w3_prof_buf[bid * 32 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+    }
+#endif
     const int q = bid >> 3;
     const int cg = q % g.ncog;
     const int region = (q / g.ncog) * 8 + (bid & 7);
@@ -721,8 +738,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    W3_STAMP(1);
 #pragma unroll 1
     for (int s = 0; s < nslabs; ++s) {
+        if (s == 1) W3_STAMP(8);
         // raw(s+1) is staged into buffer (s+1)&1 (whose last reader was the transform of slab s-1) during this slab's
         // contraction: two pieces behind the first k-step of groups 1..5 -- issued back to back the ten pieces block the
         // wave's instruction stream for ~1700 cycles (tools/prof_wino43.py), spread out they hide behind the MFMAs.  vmcnt
@@ -781,14 +800,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
         w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
         }
         // ---- V is free once every wave is here; raw(s+1) landed during this slab (last wait above)
+        if (s == 1) W3_STAMP(9);
         fix_raw(sn, (s + 1) & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (s == 1) W3_STAMP(10);
         if (!(W3_DBG & 1)) transform((s + 1) & 1);              // (after the last slab: a harmless re-transform, keeps the span branch-free)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s == 1) W3_STAMP(11);
         __builtin_amdgcn_s_barrier();
+        if (s == 1) W3_STAMP(12);
     }
     w2_wait_b<0, NT>(bv[0]);
+    W3_STAMP(2);
 
     if (W3_DBG & 4) return;
     // ---------------------------------------------------------------------- output transform G^T M G + fused epilogue
@@ -815,12 +839,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+        if (j == 1) W3_STAMP(16);
         __builtin_amdgcn_s_barrier();   // V / raw (first tile) or the previous tile's M fully consumed
+        if (j == 1) W3_STAMP(17);
         if (j == 0) w2_store_m<NT, 0, 0, 0>(acc, m_wbase);
         if (j == 1) w2_store_m<NT, (NT > 1 ? 1 : 0), 0, 0>(acc, m_wbase);
         if (j == 2) w2_store_m<NT, (NT > 2 ? 2 : 0), 0, 0>(acc, m_wbase);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j == 1) W3_STAMP(18);
         __builtin_amdgcn_s_barrier();
+        if (j == 1) W3_STAMP(19);
         const int cq0 = co0 + j * 32 + eq * 4;
         const bool quad_ok = cq0 + 3 < d.Cout;             // Cout % 4 == 0 (wino32_plan): a quad is real or padding
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
@@ -897,6 +925,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
                 }
             }
         }
+        if (j == 1) W3_STAMP(21);
         if (d.stats) {
             // sum over the 8 tiles of this wave (lane bits 3..5), then over the 4 waves through LDS
 #pragma unroll
@@ -923,6 +952,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
             }
         }
     }
+    W3_STAMP(3);
 }
 
 // eligibility + geometry of the F(3x3,2x2) path: forward-walking 2x2 taps on the in_s-subsampled input, or the 4x4 s2

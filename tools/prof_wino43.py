@@ -20,26 +20,41 @@ def main():
     ap.add_argument("--cin", type=int, default=96)
     ap.add_argument("--h", type=int, default=512)
     ap.add_argument("--w", type=int, default=1024)
+    ap.add_argument("--kernel", default="w43", choices=["w43", "w32"])
+    ap.add_argument("--case", default="down", choices=["down", "up"], help="w32: Conv2d k4 s2 96->192 / ConvTranspose2d k4 s2 384->96")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = H.load()
     Cc = args.cin
     eng = Engine(dev, record=False)
-    x = Act(torch.randn(8, args.h, args.w, Cc, device=dev))
-    w = (torch.randn(Cc, Cc, 3, 3, device=dev) * 0.05).requires_grad_(True)
-    o = eng.conv(x, w, None, None, kind="conv", k=3, stride=1, pad=1, relu=False)
+    if args.kernel == "w43":
+        kind, k, stride, Cout = "conv", 3, 1, Cc
+        x = Act(torch.randn(8, args.h, args.w, Cc, device=dev))
+        w = (torch.randn(Cc, Cc, 3, 3, device=dev) * 0.05).requires_grad_(True)
+    elif args.case == "down":
+        kind, k, stride, Cc, Cout = "conv", 4, 2, 96, 192
+        x = Act(torch.randn(8, 512, 1024, Cc, device=dev))
+        w = (torch.randn(Cout, Cc, 4, 4, device=dev) * 0.05).requires_grad_(True)
+    else:
+        kind, k, stride, Cc, Cout = "convT", 4, 2, 384, 96
+        x = Act(torch.randn(8, 256, 512, Cc, device=dev))
+        w = (torch.randn(Cc, Cout, 4, 4, device=dev) * 0.05).requires_grad_(True)
+    o = eng.conv(x, w, None, None, kind=kind, k=k, stride=stride, pad=1, relu=False)
     out_t = o.t
+
+    def run():
+        eng._run_gather(eng._launch_plan(kind, k, stride, 1, w, "fwd"), x, out_t, Cout, w)
     for _ in range(3):
-        eng._run_gather(eng._launch_plan("conv", 3, 1, 1, w, "fwd"), x, out_t, Cc, w)
+        run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    eng._run_gather(eng._launch_plan("conv", 3, 1, 1, w, "fwd"), x, out_t, Cc, w)
+    run()
     e1.record()
     torch.cuda.synchronize()
     ev_us = e0.elapsed_time(e1) * 1000.0
     buf = np.zeros(16384 * 32, dtype=np.uint64)
-    rc = lib.adh_w4_prof_read(C.c_void_p(buf.ctypes.data))
+    rc = (lib.adh_w4_prof_read if args.kernel == "w43" else lib.adh_w3_prof_read)(C.c_void_p(buf.ctypes.data))
     assert rc == 0
     b = buf.reshape(16384, 32)
     b = b[b[:, 0] != 0]
@@ -58,7 +73,10 @@ def main():
     for name, a, c in (("prologue", 0, 1), ("main loop", 1, 2), ("epilogue", 2, 3), ("total", 0, 3)):
         dt = (t[:, c] - t[:, a]) * tick_us
         print(f"  {name:10s} mean {dt.mean():7.2f} us  p10 {np.percentile(dt, 10):7.2f}  p50 {np.percentile(dt, 50):7.2f}  p90 {np.percentile(dt, 90):7.2f}")
-    for name, a, c in (("chunk 1: stage issue", 0, 1), ("transform", 1, 2), ("barrier", 2, 3), ("contraction", 3, 4), ("fix + barrier", 4, 5), ("whole chunk", 0, 5)):
+    chunk_rows = (("chunk 1: stage issue", 0, 1), ("transform", 1, 2), ("barrier", 2, 3), ("contraction", 3, 4), ("fix + barrier", 4, 5), ("whole chunk", 0, 5))
+    if args.kernel == "w32":   # (a convT launch runs one class per launch: the event time covers the four launches, the stamps the last)
+        chunk_rows = (("slab 1: contraction", 0, 1), ("fix + barrier", 1, 2), ("transform", 2, 3), ("barrier", 3, 4), ("whole slab", 0, 4))
+    for name, a, c in chunk_rows:
         dt = (tc[:, c] - tc[:, a]) * tick_us
         print(f"  {name:22s} mean {dt.mean():7.2f} us  p10 {np.percentile(dt, 10):7.2f}  p50 {np.percentile(dt, 50):7.2f}  p90 {np.percentile(dt, 90):7.2f}")
     for name, a, c in (("epilogue round 1: barrier", 0, 1), ("M write", 1, 2), ("barrier", 2, 3), ("half 0", 3, 4), ("half 1", 4, 5), ("whole round (no stats)", 0, 5)):
