@@ -62,6 +62,23 @@ __device__ __forceinline__ float adh_opaque(float v) {
 }
 __device__ __forceinline__ f32x4 adh_pksub(const f32x4& a, const f32x4& b, float m1) { return m1 * b + a; }
 
+// gfx950: an MFMA that reads a VGPR a VALU instruction wrote one or two instructions earlier gets the OLD value (measured
+// with tools/dev_wgrad32_probe.py on conv_wgrad32_kernel: the product of the frequency whose MFMA hipcc scheduled right behind the v_fmac that
+// finishes its B operand lost exactly that term).  hipcc pads VALU -> MFMA hazards for MFMA *instructions*; ours are inline
+// asm, which its hazard recogniser does not look into.  The operands therefore pass through an asm that holds two wait
+// states behind the last VALU write before any MFMA may issue.
+template <int TN>
+__device__ __forceinline__ void adh_mfma_operand_fence(float (&V)[4], float (&M)[TN][4]) {
+    if constexpr (TN == 1)
+        asm volatile("s_nop 1" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(M[0][0]), "+v"(M[0][1]), "+v"(M[0][2]), "+v"(M[0][3]));
+    if constexpr (TN == 2)
+        asm volatile("s_nop 1" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(M[0][0]), "+v"(M[0][1]), "+v"(M[0][2]), "+v"(M[0][3]),
+                     "+v"(M[1][0]), "+v"(M[1][1]), "+v"(M[1][2]), "+v"(M[1][3]));
+    if constexpr (TN == 3)
+        asm volatile("s_nop 1" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(M[0][0]), "+v"(M[0][1]), "+v"(M[0][2]), "+v"(M[0][3]),
+                     "+v"(M[1][0]), "+v"(M[1][1]), "+v"(M[1][2]), "+v"(M[1][3]), "+v"(M[2][0]), "+v"(M[2][1]), "+v"(M[2][2]), "+v"(M[2][3]));
+}
+
 // conv_rows.hip: direct forward kernel for the 2x2 / 3x3-tap gather forms (0 blocks / ADH_E_UNSUPPORTED when `d`
 // is not one of its shapes; conv_igemm.hip then takes the launch)
 int adh_rows_fwd_num_blocks(const adh_conv_desc* d);

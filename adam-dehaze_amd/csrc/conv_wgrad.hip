@@ -497,6 +497,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
                     M[j][2] = m12.y;
                     M[j][3] = t.y;
                 }
+                adh_mfma_operand_fence<TN>(V, M);   // VALU -> inline-asm MFMA hazard (common.h)
                 wr_mfma_wino<TN, 0>(acc, V, M);
                 __builtin_amdgcn_sched_barrier(0);
             }

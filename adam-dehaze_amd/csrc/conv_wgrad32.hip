@@ -1,0 +1,512 @@
+// Weight gradient of the 2x2-tap gather forms in the Winograd F(3x3, 2x2) domain, fp32 MFMA, gfx950.
+//
+// The 2x2-tap forms are what Conv2d k4 s2 (four kernel-parity classes on the stride-2 input grid) and every output-parity
+// class of ConvTranspose2d k4 s2 decompose into (conv_wgrad.hip, wgrad_rows_plan); their weight gradients are the autograd
+// backward ATen runs for those layers in the reference's training step (/root/reference models/dehazing/
+// high_intensity.py:100-118, training/train_joint.py:153).  conv_wgrad_rows_kernel<2,2,..> computes them directly: 4 MACs
+// per output pixel and (ci, co) pair.  With
+//
+//   Y(3x3) = G^T [ (A g A^T) .* (B^T d B) ] G          d: 4x4 input patch, g: 2x2 filter   (conv_wino.hip, F(3x3,2x2))
+//
+// the gradient with respect to U = A g A^T is  dU[f][ci][co] = sum over 3x3 tiles of (B^T d B)[f][tile][ci] * (G dY G^T)[f][tile][co]:
+// 16 products per tile of 9 pixels instead of 36 -- 4/9 of the MFMA work -- and dg = A^T dU A is applied once, by the
+// reduce kernel.  Same skeleton as the Winograd-domain gradient of the 3x3 layers (conv_wgrad_rows_kernel<3,3,0,TN,true>):
+// 4 waves, one per SIMD, wave w owns frequency row a = w (4 frequencies x TN n-tiles = 12 accumulator tiles, all in
+// AGPRs); a workgroup owns 32 input channels x 32 TN output channels and sweeps a contiguous range of pixel regions; the
+// raw input halo and the raw dY tile arrive by LDS-DMA, double buffered, one barrier per region; both operands are
+// transformed in registers, in the lane layout the MFMA wants (lane = channel), straight from the raw LDS images:
+//   A side: r[c] = d[rA][c] + sg d[rB][c] (row a of B^T d; rows and sign are per-wave constants),
+//           V = r0 - r2, r1 + r2, r2 - r1, r1 - r3                                           (4 packed VALU)
+//   B side: t[j] = dY[0][j] + cc dY[1][j] + dY[2][j] for a = 1, 2 (cc = +1 / -1); t[j] = dY[0][j] / dY[2][j] for a = 0 / 3,
+//           W = t0, t0 + t1 + t2, t0 - t1 + t2, t2                              (7 / 3 VALU per n-tile)
+//   (row a and column b of G carry a factor 1/2 for a, b in {1, 2}: applied by the reduce kernel.)
+// Region = 3 rows x 48 columns of the class grid = 16 tiles = 8 MFMA k-steps (lane half h takes tile column 2s + h): the
+// largest region whose halo (4 x 49 px x 32 ch) and dY tile (3 x 48 px x 32 TN ch) double-buffer in the CU's 160 KB at
+// TN = 3.  Ragged grids (the class grids are 2^k sized, 3 and 48 are not): dY pixels beyond the grid are zero-filled,
+// halo pixels beyond the image too.
+#include "common.h"
+#include <cstdlib>
+
+#define G32_TH 3
+#define G32_TW 48
+#define G32_HR 4                                  // halo rows
+#define G32_HP 49                                 // halo row pitch in pixels (the 7th DMA piece of a row writes pixel 48 only)
+#define G32_XF (G32_HR * G32_HP * 32)             // floats of the halo image
+#define G32_GROW (G32_TW * 32)                    // floats of one dY row of one n-tile
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr_g32;
+
+struct Wg32Args {
+    int ymin, xmin, xps;          // input pixel of halo (0,0) for virtual pixel (0,0); input pixels per halo pixel
+    int ntiles, nsplit, ngroups, nco_groups, tiles_x, tiles_y;
+    int cls, ncls;                // class of this launch / classes of the layer: slab[split][cls][16][KP][NcP]
+};
+
+struct Wg32TileGeom {             // wave-uniform description of one staged region
+    __amdgpu_buffer_rsrc_t xr, gr;
+    int iy0, ix0, so, sg0, vy0, vx0;
+    bool interior, g_full;
+};
+
+template <int I, int TN>
+__device__ __forceinline__ void g32_mfma_all(f32x16 (&acc)[4 * TN], const float (&V)[4], const float (&M)[TN][4]) {
+    if constexpr (I < 4 * TN) {
+        asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[I]) : "v"(V[I / TN]), "v"(M[I % TN][I / TN]));
+        g32_mfma_all<I + 1, TN>(acc, V, M);
+    }
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 1) void conv_wgrad32_kernel(const adh_conv_desc d, const Wg32Args g, float* slab) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int GF = TN * G32_TH * G32_GROW;     // floats of the dY image [TN][3][48][32]
+    constexpr int BUF = G32_XF + GF;
+    constexpr int NGP = 18 * TN;                   // DMA pieces of the dY image (8 pixels x 32 channels each)
+    constexpr int GU = (NGP + 3) / 4;              // ... per wave (at most)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    // XCD-aware decode (conv_wgrad_rows_kernel): the workgroups that share one pixel range land on one XCD
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int q = bid >> 3;
+    const int grp = q % g.ngroups;
+    const int split = (q / g.ngroups) * 8 + xcd;
+    if (split >= g.nsplit) return;
+    const int ci_tile = grp / g.nco_groups;
+    const int co_grp = grp - ci_tile * g.nco_groups;
+    const int ci0 = ci_tile * 32;
+    const int co0 = co_grp * 32 * TN;
+
+    const int per = g.ntiles / g.nsplit, rem = g.ntiles - per * g.nsplit;
+    const int t_begin = split * per + adh_min_i(split, rem);
+    const int t_end = t_begin + per + (split < rem ? 1 : 0);
+
+    // descriptors are per image; the halo descriptor's base is pixel (ymin, xmin) of the image, so every scalar offset is
+    // non-negative; lanes that would fall outside the tensor are never issued
+    const int xcs = d.in_cstride * 4 * g.xps, gcs = d.out_cstride * 4 * d.out_sx;
+    const int xrs = d.IW * d.in_cstride * 4 * g.xps, grs = d.OW * d.out_cstride * 4 * d.out_sy;
+    const float* xbase = d.in + ((int64_t)g.ymin * d.IW + g.xmin) * d.in_cstride + ci0;
+    const float* gbase = d.out + ((int64_t)d.out_oy * d.OW + d.out_ox) * d.out_cstride + co0;
+    const int64_t ximg = (int64_t)d.IH * d.IW * d.in_cstride, gimg = (int64_t)d.OH * d.OW * d.out_cstride;
+    const int xv = (lane >> 3) * xcs + (lane & 7) * 16;    // per-lane byte offsets inside one 8-pixel piece
+    const int gv = (lane >> 3) * gcs + (lane & 7) * 16;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool g_partial = co0 + 32 * TN > d.Cout;   // this group's last n-tile has channels beyond Cout
+
+    auto tile_geom = [&](int n, int ty, int tx) {
+        Wg32TileGeom t;
+        t.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase + n * ximg), 0, 0x7fffffff, 0x00020000);
+        t.gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gbase + n * gimg), 0, 0x7fffffff, 0x00020000);
+        t.vy0 = ty * G32_TH;
+        t.vx0 = tx * G32_TW;
+        t.iy0 = t.vy0 * g.xps + g.ymin;
+        t.ix0 = t.vx0 * g.xps + g.xmin;
+        t.so = t.vy0 * xrs + t.vx0 * xcs;
+        t.sg0 = t.vy0 * grs + t.vx0 * gcs;
+        t.interior = t.iy0 >= 0 && t.iy0 + (G32_HR - 1) * g.xps < d.IH && t.ix0 >= 0 && t.ix0 + (G32_HP - 1) * g.xps < d.IW;
+        t.g_full = t.vy0 + G32_TH <= d.VH && t.vx0 + G32_TW <= d.VW;
+        return t;
+    };
+    // stage region t into buffer b: this wave's share of the DMA pieces (28 of the halo, 18 TN of dY)
+    auto stage = [&](const Wg32TileGeom& t, int b) {
+        float* xs = smem + b * BUF;
+        float* gs = xs + G32_XF;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int j = wave + 4 * u;                           // < 28
+            const int pr = (j * 37) >> 8, pc = j - 7 * pr;        // j / 7, j % 7
+            float* dst = xs + (pr * G32_HP + pc * 8) * 32;
+            const int po = t.so + pr * xrs + pc * 8 * xcs;
+            const int c = pc * 8 + (lane >> 3);                   // halo column of this lane's pixel
+            if (t.interior) {
+                if (pc == 6) {
+                    if (c < G32_HP) __builtin_amdgcn_raw_ptr_buffer_load_lds(t.xr, (lds_void_ptr_g32)dst, 16, xv, po, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(t.xr, (lds_void_ptr_g32)dst, 16, xv, po, 0, 0);
+                }
+            } else {
+                const int iy = t.iy0 + pr * g.xps, ix = t.ix0 + c * g.xps;
+                const bool ok = c < G32_HP && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
+                if (ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(t.xr, (lds_void_ptr_g32)dst, 16, xv, po, 0, 0);
+                if (!ok && c < G32_HP) *reinterpret_cast<f32x4*>(dst + lane * 4) = zero4;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = wave + 4 * u;
+            if (i < NGP) {
+                const int tn = i / 18, r18 = i - 18 * tn, r = r18 / 6, cb = r18 - 6 * r;
+                float* dst = gs + ((tn * G32_TH + r) * G32_TW + cb * 8) * 32;
+                const int po = t.sg0 + r * grs + cb * 8 * gcs + tn * 128;
+                const bool ch_ok = !g_partial || co0 + tn * 32 + (lane & 7) * 4 < d.Cout;
+                if (t.g_full) {
+                    if (ch_ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(t.gr, (lds_void_ptr_g32)dst, 16, gv, po, 0, 0);
+                } else {
+                    const bool ok = t.vy0 + r < d.VH && t.vx0 + cb * 8 + (lane >> 3) < d.VW;
+                    if (ok && ch_ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(t.gr, (lds_void_ptr_g32)dst, 16, gv, po, 0, 0);
+                    if (!ok) *reinterpret_cast<f32x4*>(dst + lane * 4) = zero4;
+                }
+            }
+        }
+    };
+    if (g_partial) {   // the masked channel quads of a partial n-tile keep these zeros
+        for (int i = tid; i < 2 * BUF / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = zero4;
+        __syncthreads();
+    }
+
+    f32x16 acc[4 * TN];
+#pragma unroll
+    for (int t = 0; t < 4 * TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int tx = t_begin % g.tiles_x;
+    int ty = (t_begin / g.tiles_x) % g.tiles_y;
+    int n = t_begin / (g.tiles_x * g.tiles_y);
+    if (t_begin < t_end) stage(tile_geom(n, ty, tx), 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // per-wave constants of the operand transforms (frequency row a = wave)
+    const int rA = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rB = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = wave == 1 ? 1.f : -1.f;
+    const float cc = wave == 1 ? 1.f : -1.f;        // a = 1: dY0 + dY1 + dY2, a = 2: dY0 - dY1 + dY2
+    const int rP = wave == 3 ? 2 : 0;               // a = 0: dY row 0, a = 3: dY row 2
+    const bool single_row = wave == 0 || wave == 3;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef const volatile __attribute__((address_space(3))) float* lds_vf;   // one ds_read_b32 per element, 16-bit immediates
+
+    int cur = 0;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int ntx = tx + 1, nty = ty, nn = n;
+        if (ntx == g.tiles_x) { ntx = 0; ++nty; }
+        if (nty == g.tiles_y) { nty = 0; ++nn; }
+        if (tile + 1 < t_end) stage(tile_geom(nn, nty, ntx), cur ^ 1);
+
+        // lane (h, l31): tile column 2 s + h in k-step s, channel l31; patch / tile column c of step s sits 6 s + c pixels
+        // behind the lane's base (3 h pixels into the row)
+        lds_vf xa = (lds_vf)(smem + cur * BUF + (rA * G32_HP + 3 * h) * 32 + l31);
+        lds_vf xb = (lds_vf)(smem + cur * BUF + (rB * G32_HP + 3 * h) * 32 + l31);
+        lds_vf g0 = (lds_vf)(smem + cur * BUF + G32_XF + ((single_row ? rP : 0) * G32_TW + 3 * h) * 32 + l31);
+        f32x2 va[2][2], vb[2][2];
+        auto ld_a = [&](int s, f32x2 (&a)[2], f32x2 (&b)[2]) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                a[c] = f32x2{xa[(6 * s + 2 * c) * 32], xa[(6 * s + 2 * c + 1) * 32]};
+                b[c] = f32x2{xb[(6 * s + 2 * c) * 32], xb[(6 * s + 2 * c + 1) * 32]};
+            }
+        };
+        auto a_side = [&](const f32x2 (&a)[2], const f32x2 (&b)[2], float (&V)[4]) {
+            const f32x2 r01 = sg * b[0] + a[0];
+            const f32x2 r23 = sg * b[1] + a[1];
+            f32x2 v01, v32;   // (V0, V1) = (r0 - r2, r1 + r2), (V3, -V2) = (r1 - r3, r1 - r2)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(v01) : "v"(r01), "v"(r23));
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v32) : "v"(r01), "v"(r23));
+            V[0] = v01.x;
+            V[1] = v01.y;
+            V[2] = v32.y;   // -V2: the B side hands over -W2
+            V[3] = v32.x;
+        };
+        if (single_row) {
+            // a = 0 / 3: one dY row
+            f32x2 p[2][TN];
+            float qv[2][TN];
+            auto ld_b = [&](int s, f32x2 (&pp)[TN], float (&qq)[TN]) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    pp[j] = f32x2{g0[(j * G32_TH * G32_TW + 6 * s) * 32], g0[(j * G32_TH * G32_TW + 6 * s + 1) * 32]};
+                    qq[j] = g0[(j * G32_TH * G32_TW + 6 * s + 2) * 32];
+                }
+            };
+            ld_a(0, va[0], vb[0]);
+            ld_b(0, p[0], qv[0]);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8) {
+                    ld_a(s + 1, va[(s + 1) & 1], vb[(s + 1) & 1]);
+                    ld_b(s + 1, p[(s + 1) & 1], qv[(s + 1) & 1]);
+                }
+                float V[4], M[TN][4];
+                a_side(va[s & 1], vb[s & 1], V);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x2 t01 = p[s & 1][j];
+                    const float t2 = qv[s & 1][j];
+                    const float sm = t01.x + t2;
+                    M[j][0] = t01.x;
+                    M[j][1] = sm + t01.y;
+                    M[j][2] = t01.y - sm;   // -W2
+                    M[j][3] = t2;
+                }
+                adh_mfma_operand_fence<TN>(V, M);
+                g32_mfma_all<0, TN>(acc, V, M);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // a = 1 / 2: dY0 + cc dY1 + dY2
+            f32x2 p[2][3][TN];
+            float qv[2][3][TN];
+            auto ld_b = [&](int s, f32x2 (&pp)[3][TN], float (&qq)[3][TN]) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        pp[r][j] = f32x2{g0[((j * G32_TH + r) * G32_TW + 6 * s) * 32], g0[((j * G32_TH + r) * G32_TW + 6 * s + 1) * 32]};
+                        qq[r][j] = g0[((j * G32_TH + r) * G32_TW + 6 * s + 2) * 32];
+                    }
+            };
+            ld_a(0, va[0], vb[0]);
+            ld_b(0, p[0], qv[0]);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8) {
+                    ld_a(s + 1, va[(s + 1) & 1], vb[(s + 1) & 1]);
+                    ld_b(s + 1, p[(s + 1) & 1], qv[(s + 1) & 1]);
+                }
+                float V[4], M[TN][4];
+                a_side(va[s & 1], vb[s & 1], V);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x2 t01 = p[s & 1][0][j] + p[s & 1][2][j];
+                    t01 = cc * p[s & 1][1][j] + t01;
+                    float t2 = qv[s & 1][0][j] + qv[s & 1][2][j];
+                    t2 = cc * qv[s & 1][1][j] + t2;
+                    const float sm = t01.x + t2;
+                    M[j][0] = t01.x;
+                    M[j][1] = sm + t01.y;
+                    M[j][2] = t01.y - sm;   // -W2
+                    M[j][3] = t2;
+                }
+                adh_mfma_operand_fence<TN>(V, M);
+                g32_mfma_all<0, TN>(acc, V, M);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+        tx = ntx; ty = nty; n = nn;
+    }
+
+    // partial result -> slab[split][cls][f = 4*wave + b][KP][NcP]
+    const int KP = d.Cin;
+    float* sbase = slab + (((size_t)split * g.ncls + g.cls) * 16 + wave * 4) * KP * d.NcP;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float* base = sbase + ((size_t)b * KP + ci0) * d.NcP + co0 + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                base[(size_t)i * d.NcP] = acc[b * TN + j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct Wg32Class {
+    int ymin, xmin, xps;
+    int tap0, tap_sy, tap_sx, rev;   // kernel tap (ty, tx) of the class is tap index tap0 + ty tap_sy + tx tap_sx of d's KH x KW taps;
+};                                   // rev: taps walk backwards, halo offset (hy, hx) belongs to tap (1 - hy, 1 - hx)
+struct Wg32Plan {
+    int ncls, TN;
+    Wg32Args base;
+    Wg32Class cls[4];
+};
+
+// the shapes conv_wgrad.hip's wgrad_rows_plan hands to conv_wgrad_rows_kernel<2,2,..> (same class decomposition), without its
+// grid-alignment conditions
+static int wgrad32_plan(const adh_conv_desc* d, int nsplit, Wg32Plan* p) {
+    static const bool enabled = !(getenv("ADH_WINO32_WGRAD") && atoi(getenv("ADH_WINO32_WGRAD")) == 0);   // A/B switch
+    if (!enabled || !d) return 0;
+    if (d->Cin % 32 != 0 || d->Cout % 4 != 0 || d->NcP != adh_round_up(d->Cout, 32)) return 0;
+    if (d->in_cstride % 4 != 0 || d->out_cstride % 4 != 0) return 0;
+    if (d->in_sy != d->in_sx || d->dstep_y != d->dstep_x || d->out_sy != d->out_sx) return 0;
+    if (d->VH < 1 || d->VW < 1) return 0;
+    if ((d->VH - 1) * d->out_sy + d->out_oy >= d->OH || (d->VW - 1) * d->out_sx + d->out_ox >= d->OW) return 0;
+    if ((int64_t)(d->IH + 8) * d->IW * d->in_cstride * 4 >= (int64_t)1 << 31) return 0;
+    if ((int64_t)d->OH * d->OW * d->out_cstride * 4 >= (int64_t)1 << 31) return 0;
+    const int t = d->NcP / 32;
+    p->TN = t % 3 == 0 ? 3 : (t % 2 == 0 ? 2 : 1);
+    Wg32Args& b = p->base;
+    b.tiles_x = adh_ceil_div(d->VW, G32_TW);
+    b.tiles_y = adh_ceil_div(d->VH, G32_TH);
+    b.ntiles = b.tiles_x * b.tiles_y * d->N;
+    b.nsplit = nsplit;
+    b.nco_groups = d->NcP / (32 * p->TN);
+    b.ngroups = (d->Cin / 32) * b.nco_groups;
+    const int s = d->in_sy, ds = d->dstep_y;
+    if (d->KH == 2 && d->KW == 2 && (ds == s || ds == -s) && (s == 1 || s == 2)) {
+        p->ncls = 1;
+        Wg32Class& c = p->cls[0];
+        c.xps = s;
+        c.rev = ds < 0;
+        c.ymin = d->dy0 + (ds < 0 ? ds : 0);
+        c.xmin = d->dx0 + (ds < 0 ? ds : 0);
+        c.tap0 = 0; c.tap_sy = 2; c.tap_sx = 1;
+        return 1;
+    }
+    if (d->KH == 4 && d->KW == 4 && s == 2 && ds == 1) {
+        // Conv2d k4 s2: kernel index ky = 2 ty + py reads input row 2 (vy + ty) + dy0 + py
+        p->ncls = 4;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                Wg32Class& c = p->cls[py * 2 + px];
+                c.xps = 2;
+                c.rev = 0;
+                c.ymin = d->dy0 + py;
+                c.xmin = d->dx0 + px;
+                c.tap0 = py * 4 + px; c.tap_sy = 8; c.tap_sx = 2;
+            }
+        return 1;
+    }
+    return 0;
+}
+
+extern "C" int adh_conv_wgrad_wino32_groups(const adh_conv_desc* d) {
+    if (!d) return ADH_E_ARG;
+    Wg32Plan p;
+    return wgrad32_plan(d, 1, &p) ? p.base.ngroups : 0;
+}
+
+// frequency slabs the caller must provide per pixel split: 16 per class
+extern "C" int adh_conv_wgrad_wino32_classes(const adh_conv_desc* d) {
+    if (!d) return ADH_E_ARG;
+    Wg32Plan p;
+    return wgrad32_plan(d, 1, &p) ? p.ncls : 0;
+}
+
+extern "C" int adh_conv_wgrad_wino32_tiles(const adh_conv_desc* d) {
+    if (!d) return ADH_E_ARG;
+    Wg32Plan p;
+    return wgrad32_plan(d, 1, &p) ? p.base.ntiles : 0;
+}
+
+extern "C" int adh_conv_wgrad_wino32(void* stream, const adh_conv_desc* d, float* slab, int nsplit) {
+    if (!d || !slab || nsplit < 1 || !d->in || !d->out) return ADH_E_ARG;
+    Wg32Plan p;
+    if (!wgrad32_plan(d, nsplit, &p)) return ADH_E_UNSUPPORTED;
+    if (((uintptr_t)d->in & 15) || ((uintptr_t)d->out & 15)) return ADH_E_ARG;
+    const int lds = 2 * (G32_XF + p.TN * G32_TH * G32_GROW) * 4;
+    const int nblocks = ((nsplit + 7) / 8) * p.base.ngroups * 8;
+    hipStream_t s = (hipStream_t)stream;
+    for (int c = 0; c < p.ncls; ++c) {
+        Wg32Args a = p.base;
+        a.ymin = p.cls[c].ymin;
+        a.xmin = p.cls[c].xmin;
+        a.xps = p.cls[c].xps;
+        a.cls = c;
+        a.ncls = p.ncls;
+#define G32_CASE(tn_) \
+        if (p.TN == tn_) { \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad32_kernel<tn_>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipLaunchKernelGGL((conv_wgrad32_kernel<tn_>), dim3(nblocks), dim3(256), lds, s, *d, a, slab); \
+        }
+        G32_CASE(3) G32_CASE(2) G32_CASE(1)
+#undef G32_CASE
+        const int rc = adh_check_launch();
+        if (rc) return rc;
+    }
+    return ADH_OK;
+}
+
+struct Wg32Taps {
+    int ncls;
+    int tap0[4], tap_sy[4], tap_sx[4], rev[4];
+};
+
+// dst(layout L) (+)= A^T (scaled sum over splits of slab[s][cls][16][KP][NcP]) A per class, scattered to the class's taps.
+// A = [[1,0],[1,1],[1,-1],[0,-1]]; rows / columns 1, 2 of the slab carry the deferred factor 1/2 of G.
+__global__ void wgrad_reduce_wino32_kernel(const float* __restrict__ slab, int nsplit, int KP, int NcP, const adh_wlayout L,
+                                           const Wg32Taps tp, float* __restrict__ dst, int accumulate) {
+    const int64_t total = (int64_t)tp.ncls * L.K * L.Nc;
+    const int64_t fstride = (int64_t)KP * NcP, cls_stride = 16 * fstride, split_stride = tp.ncls * cls_stride;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % L.Nc);
+        int64_t r = idx / L.Nc;
+        const int k = (int)(r % L.K);
+        const int c = (int)(r / L.K);
+        const float* p = slab + c * cls_stride + (int64_t)k * NcP + n;
+        float u[4][4];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            float s0 = 0.f, s1 = 0.f;
+            int sp = 0;
+            for (; sp + 2 <= nsplit; sp += 2) {
+                s0 += p[(int64_t)sp * split_stride + f * fstride];
+                s1 += p[(int64_t)(sp + 1) * split_stride + f * fstride];
+            }
+            if (sp < nsplit) s0 += p[(int64_t)sp * split_stride + f * fstride];
+            const int a = f >> 2, b = f & 3;
+            const float sc = ((a == 1 || a == 2) ? 0.5f : 1.f) * ((b == 1 || b == 2) ? 0.5f : 1.f);
+            u[a][b] = sc * (s0 + s1);
+        }
+        float t[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            t[0][b] = u[0][b] + u[1][b] + u[2][b];
+            t[1][b] = u[1][b] - u[2][b] - u[3][b];
+        }
+#pragma unroll
+        for (int hy = 0; hy < 2; ++hy) {
+            const float w2[2] = {t[hy][0] + t[hy][1] + t[hy][2], t[hy][1] - t[hy][2] - t[hy][3]};
+#pragma unroll
+            for (int hx = 0; hx < 2; ++hx) {
+                const int ty = tp.rev[c] ? 1 - hy : hy, tx = tp.rev[c] ? 1 - hx : hx;
+                const int tap = tp.tap0[c] + ty * tp.tap_sy[c] + tx * tp.tap_sx[c];
+                const int tyy = tap / L.KWt, txx = tap - tyy * L.KWt;
+                const int64_t off = (int64_t)L.tap_off0 + tyy * L.tap_off_sy + txx * L.tap_off_sx + (int64_t)k * L.stride_k +
+                                    (int64_t)n * L.stride_n;
+                dst[off] = accumulate ? dst[off] + w2[hx] : w2[hx];
+            }
+        }
+    }
+}
+
+// slab[0] = sum over splits (fixed order), 16 bytes per lane, eight independent loads in flight
+__global__ __launch_bounds__(256) void wgrad32_sum_splits_kernel(float* __restrict__ slab, int nsplit, int64_t n4) {
+    f32x4* s4 = reinterpret_cast<f32x4*>(slab);
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += s4[(int64_t)(sp + u) * n4 + i];
+        }
+        for (; sp < nsplit; ++sp) a[0] += s4[(int64_t)sp * n4 + i];
+        s4[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+}
+
+extern "C" int adh_wgrad_reduce_wino32(void* stream, float* slab, int nsplit, const adh_conv_desc* d, int KP, int NcP,
+                                       const adh_wlayout* L, float* dst, int accumulate) {
+    if (!slab || !L || !dst || !d || nsplit < 1 || (NcP & 3)) return ADH_E_ARG;
+    Wg32Plan p;
+    if (!wgrad32_plan(d, nsplit, &p)) return ADH_E_UNSUPPORTED;
+    if (L->KHt * L->KWt != d->KH * d->KW) return ADH_E_ARG;
+    Wg32Taps tp;
+    tp.ncls = p.ncls;
+    for (int c = 0; c < 4; ++c) {
+        const Wg32Class& k = p.cls[c < p.ncls ? c : 0];
+        tp.tap0[c] = k.tap0; tp.tap_sy[c] = k.tap_sy; tp.tap_sx[c] = k.tap_sx; tp.rev[c] = k.rev;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (nsplit > 1) {
+        const int64_t n4 = (int64_t)p.ncls * 16 * KP * NcP / 4;
+        hipLaunchKernelGGL(wgrad32_sum_splits_kernel, dim3(adh_min_i(adh_ceil_div(n4, 256), 2048)), dim3(256), 0, s, slab, nsplit, n4);
+    }
+    const int64_t total = (int64_t)p.ncls * L->K * L->Nc;
+    hipLaunchKernelGGL(wgrad_reduce_wino32_kernel, dim3(adh_min_i(adh_ceil_div(total, 64), 16384)), dim3(64), 0, s, slab, 1, KP,
+                       NcP, *L, tp, dst, accumulate);
+    return adh_check_launch();
+}

@@ -515,6 +515,19 @@ class Engine:
                        work=2.0 * d.N * d.VH * d.VW * T * L.K * L.Nc, work_exec=2.0 * d.N * d.VH * d.VW * 4 * L.K * L.Nc)
                 H.call("adh_wgrad_reduce_wino", slab.data_ptr(), nsplit, KP, NcP, C.byref(L), dw.data_ptr(), 0)
                 continue
+            w32_groups = H.value("adh_conv_wgrad_wino32_groups", C.byref(d)) if USE_WINOGRAD else 0
+            if w32_groups:
+                # the 2x2-tap forms (k4 s2 / transposed layers): accumulate in the F(3x3,2x2) domain, 16 frequency slabs per
+                # class, A^T(.)A in the reduce
+                ncls = H.value("adh_conv_wgrad_wino32_classes", C.byref(d))
+                nsplit = _rows_nsplit(w32_groups, H.value("adh_conv_wgrad_wino32_tiles", C.byref(d)))
+                while nsplit * ncls * 16 * KP * NcP * 4 > (1 << 30) and nsplit > 1:
+                    nsplit //= 2
+                slab = self._f(nsplit * ncls * 16 * KP * NcP)
+                H.call("adh_conv_wgrad_wino32", C.byref(d), slab.data_ptr(), nsplit,
+                       work=2.0 * d.N * d.VH * d.VW * T * L.K * L.Nc, work_exec=2.0 * d.N * d.VH * d.VW * T * (4.0 / 9.0) * L.K * L.Nc)
+                H.call("adh_wgrad_reduce_wino32", slab.data_ptr(), nsplit, C.byref(d), KP, NcP, C.byref(L), dw.data_ptr(), 0)
+                continue
             nsplit = max(1, min(ntiles_est, max(1, 1024 // groups), 512))
             rows_groups = H.value("adh_conv_wgrad_groups", C.byref(d))
             if rows_groups:

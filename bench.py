@@ -119,7 +119,7 @@ def cpu_baseline(h, w, threads):
 
 
 _PMC_PREFIX = {"adh_conv_wino43_forward": "void conv_wino43_kernel<", "adh_conv_wino_forward": "void conv_wino_kernel<", "adh_conv_wino32_forward": "void conv_wino32_kernel<",
-               "adh_conv_wgrad_wino": "void conv_wgrad_rows_kernel<3, 3, false", "adh_conv_wgrad": "void conv_wgrad_",
+               "adh_conv_wgrad_wino": "void conv_wgrad_rows_kernel<3, 3, false", "adh_conv_wgrad_wino32": "void conv_wgrad32_kernel<", "adh_conv_wgrad": "void conv_wgrad_",
                "adh_conv_forward": "void conv_rows_kernel<"}
 
 
@@ -281,6 +281,7 @@ CONV_FAMILIES = {
     "adh_conv_wino32_forward": "conv_wino32_kernel (Winograd F(3x3,2x2) fwd + dgrad of the k4 s2 / transposed layers)",
     "adh_conv_forward": "conv_rows_kernel / conv_igemm_kernel (direct fwd + dgrad launches: stems, heads, ragged shapes)",
     "adh_conv_wgrad_wino": "conv_wgrad_rows_kernel<WINO> (Winograd-domain weight gradients of 3x3 s1)",
+    "adh_conv_wgrad_wino32": "conv_wgrad32_kernel (F(3x3,2x2)-domain weight gradients of the k4 s2 / transposed layers)",
     "adh_conv_wgrad": "conv_wgrad_rows_kernel / conv_wgrad_kernel (direct weight gradients)",
     "adh_conv_wgrad_wino43": "conv_wgrad_wino43_kernel (F(4x4,3x3)-domain weight gradients)",
     "adh_conv_stem_forward": "conv_stem_fwd_kernel (7x7 stem, 16x16x4 tiles)",

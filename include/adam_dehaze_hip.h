@@ -177,6 +177,22 @@ int adh_conv_wgrad_wino(void* stream, const adh_conv_desc* d, float* slab, int n
 int adh_wgrad_reduce_wino(void* stream, float* slab /* scratch: split 0 receives the sum */, int nsplit, int KP, int NcP,
                           const adh_wlayout* L, float* dst, int accumulate);
 
+/* Winograd F(3x3,2x2)-domain weight gradient of the 2x2-tap gather forms (conv_wgrad32.hip): every output-parity class of
+ * ConvTranspose2d k4 s2 p1 (KH = KW = 2 descriptors, dstep = +-in_s) and Conv2d k4 s2 p1 (KH = KW = 4, in_s = 2: four
+ * kernel-parity classes inside one call), Cin % 32 == 0, any grid size, at 4/9 of the direct MFMA work.
+ * adh_conv_wgrad_wino32_groups(d): workgroups per pixel split (0 = not eligible, use adh_conv_wgrad);
+ * _classes(d): 1 or 4; _tiles(d): 3x48-pixel regions per class (to choose nsplit).  slab: nsplit * classes * 16 * Cin * NcP
+ * floats, d->in = x, d->out = dL/dy as for adh_conv_wgrad; adh_wgrad_reduce_wino32 sums the splits (in place), applies
+ * A^T (.) A with G's deferred factors and scatters every class's 2x2 taps into layout L (KHt*KWt = d->KH*d->KW).
+ * Replaces the weight half of ATen's conv2d / conv_transpose2d backward for the down / up-sampling layers
+ * (/root/reference models/dehazing/high_intensity.py:100-118, medium_intensity.py:53,63). */
+int adh_conv_wgrad_wino32_groups(const adh_conv_desc* d);
+int adh_conv_wgrad_wino32_classes(const adh_conv_desc* d);
+int adh_conv_wgrad_wino32_tiles(const adh_conv_desc* d);
+int adh_conv_wgrad_wino32(void* stream, const adh_conv_desc* d, float* slab, int nsplit);
+int adh_wgrad_reduce_wino32(void* stream, float* slab /* scratch: split 0 receives the sum */, int nsplit,
+                            const adh_conv_desc* d, int KP, int NcP, const adh_wlayout* L, float* dst, int accumulate);
+
 /* Packed small-Cin weight gradient (7x7 stems, Cin <= 8 stored with cstride 8): call adh_conv_wgrad with
  * KW = ceil(kw/4), dstep_x = 4, Cin = 8 -- the 32-wide MFMA row tile then spans 4 adjacent pixels x 8
  * channels -- and unpack slab[s][ky*KWg + kxg][kxl*8 + ci][NcP] into OIHW with this call. */

@@ -1,6 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against (a) the golden fixtures generated from the
 reference and (b) the CPU oracle on seeded inputs.  Tolerance: dehazed tensors / losses within 1e-3
 fp32 (BASELINE.json north_star); tests use 2e-4 for outputs and 2e-3 relative for gradients."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -9,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 import adam_dehaze_amd as A
+from adam_dehaze_amd import _hip as H
 from adam_dehaze_amd.engine import Act, Engine
 from adam_dehaze_amd.layers import AttentionBlock, ConvBlock, ResidualBlock
 from oracle import ref_cpu as R
@@ -423,6 +425,62 @@ def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, algo, monkey
     scale = float(ref.abs().max())
     assert float((got[False] - ref).abs().max()) < 2e-5 * scale
     assert float((got[True] - ref).abs().max()) < 2e-5 * scale
+
+@pytest.mark.parametrize("kind,N,Ci,Co,Hh,Ww", [
+    ("conv", 2, 32, 192, 16, 128),     # k4 s2, four kernel-parity classes, TN = 3, class grid 8 x 64: ragged in both directions
+    ("conv", 1, 96, 64, 24, 64),       # TN = 2
+    ("conv", 1, 32, 32, 12, 192),      # TN = 1, class grid 6 x 96: exact regions
+    ("conv", 3, 64, 96, 6, 20),        # grid smaller than one region, image seams inside a split
+    ("conv", 1, 32, 48, 32, 200),      # partial last n-tile
+    ("convT", 2, 96, 32, 9, 50),       # transposed: four output-parity class descriptors with reversed taps, ragged
+    ("convT", 1, 64, 96, 24, 48),      # exact regions
+    ("convT", 1, 384, 96, 16, 64),     # the headline up-sampling layer's channels
+])
+def test_wino32_weight_gradient_matches_direct(kind, N, Ci, Co, Hh, Ww, monkeypatch):
+    """F(3x3,2x2)-domain weight gradient of the 2x2-tap forms (conv_wgrad32_kernel + adh_wgrad_reduce_wino32) against the
+    direct row-split / general kernels (ADH_WINOGRAD off) and the fp64 definition, for Conv2d k4 s2 p1 and
+    ConvTranspose2d k4 s2 p1 (/root/reference models/dehazing/high_intensity.py:100-118) on exact, ragged and
+    smaller-than-a-region class grids."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(Ci + 7 * Hh)
+    x = torch.randn(N, Hh, Ww, Ci, generator=g)
+    if kind == "conv":
+        gy = torch.randn(N, Hh // 2, Ww // 2, Co, generator=g)
+        w = torch.zeros(Co, Ci, 4, 4, device=DEV, requires_grad=True)
+        ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Co, Ci, 4, 4), gy.permute(0, 3, 1, 2).double(),
+                                          stride=2, padding=1)
+    else:
+        gy = torch.randn(N, 2 * Hh, 2 * Ww, Co, generator=g)
+        w = torch.zeros(Ci, Co, 4, 4, device=DEV, requires_grad=True)
+        wr = torch.zeros(Ci, Co, 4, 4, dtype=torch.float64, requires_grad=True)
+        out = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wr, stride=2, padding=1)
+        (out * gy.permute(0, 3, 1, 2).double()).sum().backward()
+        ref = wr.grad
+    got = {}
+    for wino in (False, True):
+        monkeypatch.setattr(E, "USE_WINOGRAD", wino)
+        eng = Engine(torch.device(DEV), record=False)
+        plans = eng._launch_plan(kind, 4, 2, 1, w, "fwd")
+        if wino:
+            assert all(H.value("adh_conv_wgrad_wino32_groups", C.byref(_wgrad_desc(eng, plans, pl, x, gy, Co))) > 0 for pl in plans)
+        got[wino] = eng._wgrad(plans, Act(x.to(DEV)), gy.to(DEV), Co, w).cpu().double().clone()
+    scale = float(ref.abs().max())
+    assert float((got[False] - ref).abs().max()) < 2e-5 * scale
+    assert float((got[True] - ref).abs().max()) < 2e-5 * scale
+
+
+def _wgrad_desc(eng, plans, plan, x, gy, Co):
+    """the descriptor Engine._wgrad builds for one (layout, geometry) plan (to ask the library which kernel takes it)"""
+    L, gm = plan
+    NcP = (L.Nc + 31) // 32 * 32
+    if gm["vgrid"] == "in":
+        VH = (gy.shape[1] - gm["out_o"][0] + 1) // 2
+        VW = (gy.shape[2] - gm["out_o"][1] + 1) // 2
+    else:
+        VH, VW = gy.shape[1], gy.shape[2]
+    return eng._conv_desc(Act(x.to(DEV)), (L.K + 3) // 4 * 4, gy.to(DEV), (Co + 3) // 4 * 4, NcP, VH, VW, gm["KH"], gm["KW"],
+                          gm["in_s"], gm["out_s"], gm["out_o"], gm["dy0"], gm["dx0"], gm["dstep"])
+
 
 @pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 3, 16, 13, 70), (1, 16, 16, 8, 64), (2, 16, 16, 21, 130), (1, 48, 3, 12, 64),
                                            (2, 48, 3, 9, 75), (1, 3, 16, 4, 5)])
