@@ -252,10 +252,13 @@ __device__ __forceinline__ void wr_mfma_all(f32x16 (&acc)[T * TN], const float (
 }
 
 // Winograd mode: acc[b*TN + j] += V[b] (x) M[j][b] for the wave's four frequencies b and TN n-tiles
+// (operands written by VALU instructions just before: the MFMA carries two wait states of its own -- a VALU -> MFMA
+// hazard hipcc pads for MFMA instructions but cannot see inside inline asm; common.h, adh_mfma_operand_fence)
 template <int TN, int I>
 __device__ __forceinline__ void wr_mfma_wino(f32x16 (&acc)[4 * TN], const float (&V)[4], const float (&M)[TN][4]) {
     if constexpr (I < 4 * TN) {
-        wr_mfma<I>(acc[I], V[I / TN], M[I % TN][I / TN]);
+        static_assert(4 * TN <= 16, "all Winograd-mode accumulators sit in AGPRs");
+        asm("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[I]) : "v"(V[I / TN]), "v"(M[I % TN][I / TN]));
         wr_mfma_wino<TN, I + 1>(acc, V, M);
     }
 }
@@ -497,7 +500,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
                     M[j][2] = m12.y;
                     M[j][3] = t.y;
                 }
-                adh_mfma_operand_fence<TN>(V, M);   // VALU -> inline-asm MFMA hazard (common.h)
                 wr_mfma_wino<TN, 0>(acc, V, M);
                 __builtin_amdgcn_sched_barrier(0);
             }

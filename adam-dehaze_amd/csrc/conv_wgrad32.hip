@@ -27,6 +27,9 @@
 #include "common.h"
 #include <cstdlib>
 
+#ifndef G32_DBG
+#define G32_DBG 0   // dev builds (timing only, wrong results): 1 = stage only the first region, 2 = skip the contraction
+#endif
 #define G32_TH 3
 #define G32_TW 48
 #define G32_HR 4                                  // halo rows
@@ -51,7 +54,8 @@ struct Wg32TileGeom {             // wave-uniform description of one staged regi
 template <int I, int TN>
 __device__ __forceinline__ void g32_mfma_all(f32x16 (&acc)[4 * TN], const float (&V)[4], const float (&M)[TN][4]) {
     if constexpr (I < 4 * TN) {
-        asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[I]) : "v"(V[I / TN]), "v"(M[I % TN][I / TN]));
+        // (s_nop 1: two wait states between the VALU instruction that wrote an operand and the MFMA -- see adh_mfma_operand_fence)
+        asm("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[I]) : "v"(V[I / TN]), "v"(M[I % TN][I / TN]));
         g32_mfma_all<I + 1, TN>(acc, V, M);
     }
 }
@@ -176,9 +180,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32_kernel(const adh_conv_des
     const int rA = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rB = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sg = wave == 1 ? 1.f : -1.f;
-    const float cc = wave == 1 ? 1.f : -1.f;        // a = 1: dY0 + dY1 + dY2, a = 2: dY0 - dY1 + dY2
-    const int rP = wave == 3 ? 2 : 0;               // a = 0: dY row 0, a = 3: dY row 2
-    const bool single_row = wave == 0 || wave == 3;
+    const float k0 = wave == 3 ? 0.f : 1.f, k1 = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f), k2 = wave == 0 ? 0.f : 1.f;   // row a of G (x2 for a = 1, 2)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef const volatile __attribute__((address_space(3))) float* lds_vf;   // one ds_read_b32 per element, 16-bit immediates
 
@@ -187,13 +189,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32_kernel(const adh_conv_des
         int ntx = tx + 1, nty = ty, nn = n;
         if (ntx == g.tiles_x) { ntx = 0; ++nty; }
         if (nty == g.tiles_y) { nty = 0; ++nn; }
-        if (tile + 1 < t_end) stage(tile_geom(nn, nty, ntx), cur ^ 1);
+        if (!(G32_DBG & 1) && tile + 1 < t_end) stage(tile_geom(nn, nty, ntx), cur ^ 1);
 
         // lane (h, l31): tile column 2 s + h in k-step s, channel l31; patch / tile column c of step s sits 6 s + c pixels
         // behind the lane's base (3 h pixels into the row)
         lds_vf xa = (lds_vf)(smem + cur * BUF + (rA * G32_HP + 3 * h) * 32 + l31);
         lds_vf xb = (lds_vf)(smem + cur * BUF + (rB * G32_HP + 3 * h) * 32 + l31);
-        lds_vf g0 = (lds_vf)(smem + cur * BUF + G32_XF + ((single_row ? rP : 0) * G32_TW + 3 * h) * 32 + l31);
+        lds_vf g0 = (lds_vf)(smem + cur * BUF + G32_XF + (3 * h) * 32 + l31);
         f32x2 va[2][2], vb[2][2];
         auto ld_a = [&](int s, f32x2 (&a)[2], f32x2 (&b)[2]) {
 #pragma unroll
@@ -213,80 +215,47 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32_kernel(const adh_conv_des
             V[2] = v32.y;   // -V2: the B side hands over -W2
             V[3] = v32.x;
         };
-        if (single_row) {
-            // a = 0 / 3: one dY row
-            f32x2 p[2][TN];
-            float qv[2][TN];
-            auto ld_b = [&](int s, f32x2 (&pp)[TN], float (&qq)[TN]) {
+        // One instruction stream for all four waves: t[j] = k0 dY[0][j] + k1 dY[1][j] + k2 dY[2][j] with the wave's row of G as
+        // (k0, k1, k2) = (1,0,0), (1,1,1), (1,-1,1), (0,0,1).  (Waves 0 and 3 could read one row instead of three, but the
+        // waves meet at the barrier anyway, and a run-time branch around the MFMA loops makes hipcc move the accumulators
+        // between register classes at the join: 200 v_accvgpr_write per region, measured.)
+        f32x2 p[2][3][TN];
+        float qv[2][3][TN];
+        auto ld_b = [&](int s, f32x2 (&pp)[3][TN], float (&qq)[3][TN]) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    pp[j] = f32x2{g0[(j * G32_TH * G32_TW + 6 * s) * 32], g0[(j * G32_TH * G32_TW + 6 * s + 1) * 32]};
-                    qq[j] = g0[(j * G32_TH * G32_TW + 6 * s + 2) * 32];
+                    pp[r][j] = f32x2{g0[((j * G32_TH + r) * G32_TW + 6 * s) * 32], g0[((j * G32_TH + r) * G32_TW + 6 * s + 1) * 32]};
+                    qq[r][j] = g0[((j * G32_TH + r) * G32_TW + 6 * s + 2) * 32];
                 }
-            };
-            ld_a(0, va[0], vb[0]);
-            ld_b(0, p[0], qv[0]);
+        };
+        ld_a(0, va[0], vb[0]);
+        ld_b(0, p[0], qv[0]);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s + 1 < 8) {
-                    ld_a(s + 1, va[(s + 1) & 1], vb[(s + 1) & 1]);
-                    ld_b(s + 1, p[(s + 1) & 1], qv[(s + 1) & 1]);
-                }
-                float V[4], M[TN][4];
-                a_side(va[s & 1], vb[s & 1], V);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const f32x2 t01 = p[s & 1][j];
-                    const float t2 = qv[s & 1][j];
-                    const float sm = t01.x + t2;
-                    M[j][0] = t01.x;
-                    M[j][1] = sm + t01.y;
-                    M[j][2] = t01.y - sm;   // -W2
-                    M[j][3] = t2;
-                }
-                adh_mfma_operand_fence<TN>(V, M);
-                g32_mfma_all<0, TN>(acc, V, M);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < ((G32_DBG & 2) ? 0 : 8); ++s) {
+            if (s + 1 < 8) {
+                ld_a(s + 1, va[(s + 1) & 1], vb[(s + 1) & 1]);
+                ld_b(s + 1, p[(s + 1) & 1], qv[(s + 1) & 1]);
             }
-        } else {
-            // a = 1 / 2: dY0 + cc dY1 + dY2
-            f32x2 p[2][3][TN];
-            float qv[2][3][TN];
-            auto ld_b = [&](int s, f32x2 (&pp)[3][TN], float (&qq)[3][TN]) {
+            float V[4], M[TN][4];
+            a_side(va[s & 1], vb[s & 1], V);
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        pp[r][j] = f32x2{g0[((j * G32_TH + r) * G32_TW + 6 * s) * 32], g0[((j * G32_TH + r) * G32_TW + 6 * s + 1) * 32]};
-                        qq[r][j] = g0[((j * G32_TH + r) * G32_TW + 6 * s + 2) * 32];
-                    }
-            };
-            ld_a(0, va[0], vb[0]);
-            ld_b(0, p[0], qv[0]);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s + 1 < 8) {
-                    ld_a(s + 1, va[(s + 1) & 1], vb[(s + 1) & 1]);
-                    ld_b(s + 1, p[(s + 1) & 1], qv[(s + 1) & 1]);
-                }
-                float V[4], M[TN][4];
-                a_side(va[s & 1], vb[s & 1], V);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x2 t01 = p[s & 1][0][j] + p[s & 1][2][j];
-                    t01 = cc * p[s & 1][1][j] + t01;
-                    float t2 = qv[s & 1][0][j] + qv[s & 1][2][j];
-                    t2 = cc * qv[s & 1][1][j] + t2;
-                    const float sm = t01.x + t2;
-                    M[j][0] = t01.x;
-                    M[j][1] = sm + t01.y;
-                    M[j][2] = t01.y - sm;   // -W2
-                    M[j][3] = t2;
-                }
-                adh_mfma_operand_fence<TN>(V, M);
-                g32_mfma_all<0, TN>(acc, V, M);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < TN; ++j) {
+                f32x2 t01 = k0 * p[s & 1][0][j];
+                t01 = k1 * p[s & 1][1][j] + t01;
+                t01 = k2 * p[s & 1][2][j] + t01;
+                float t2 = k0 * qv[s & 1][0][j];
+                t2 = k1 * qv[s & 1][1][j] + t2;
+                t2 = k2 * qv[s & 1][2][j] + t2;
+                const float sm = t01.x + t2;
+                M[j][0] = t01.x;
+                M[j][1] = sm + t01.y;
+                M[j][2] = t01.y - sm;   // -W2
+                M[j][3] = t2;
             }
+            g32_mfma_all<0, TN>(acc, V, M);
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -324,8 +293,15 @@ struct Wg32Plan {
 // the shapes conv_wgrad.hip's wgrad_rows_plan hands to conv_wgrad_rows_kernel<2,2,..> (same class decomposition), without its
 // grid-alignment conditions
 static int wgrad32_plan(const adh_conv_desc* d, int nsplit, Wg32Plan* p) {
-    static const bool enabled = !(getenv("ADH_WINO32_WGRAD") && atoi(getenv("ADH_WINO32_WGRAD")) == 0);   // A/B switch
-    if (!enabled || !d) return 0;
+    // ADH_WINO32_WGRAD: 0 = off, 1 (default) = where it wins, 2 = every eligible shape
+    const char* env = getenv("ADH_WINO32_WGRAD");   // (read per call: the tests switch it)
+    const int mode = env ? atoi(env) : 1;
+    if (!mode || !d) return 0;
+    // The kernel is bound by the issue of its LDS-DMA pieces, not by its MFMAs (82 pieces per 96 MFMAs and wave: the same
+    // bytes per pixel as the direct kernel stages, for 4/9 of the MFMAs): measured at the headline shapes, ConvTranspose
+    // 384 -> 96 10.25 -> 8.4 ms, but Conv2d k4 s2 96 -> 192 5.2 -> 6.2 ms.  The four-class (k4 s2) form therefore stays on
+    // the direct kernel unless forced.
+    if (mode < 2 && d->KH == 4) return 0;
     if (d->Cin % 32 != 0 || d->Cout % 4 != 0 || d->NcP != adh_round_up(d->Cout, 32)) return 0;
     if (d->in_cstride % 4 != 0 || d->out_cstride % 4 != 0) return 0;
     if (d->in_sy != d->in_sx || d->dstep_y != d->dstep_x || d->out_sy != d->out_sx) return 0;

@@ -442,6 +442,7 @@ def test_wino32_weight_gradient_matches_direct(kind, N, Ci, Co, Hh, Ww, monkeypa
     ConvTranspose2d k4 s2 p1 (/root/reference models/dehazing/high_intensity.py:100-118) on exact, ragged and
     smaller-than-a-region class grids."""
     import adam_dehaze_amd.engine as E
+    monkeypatch.setenv("ADH_WINO32_WGRAD", "2")    # every eligible shape (by default the k4 s2 form stays on the direct kernel)
     g = torch.Generator().manual_seed(Ci + 7 * Hh)
     x = torch.randn(N, Hh, Ww, Ci, generator=g)
     if kind == "conv":
