@@ -187,11 +187,13 @@ def _rank_one_wgrad_ref(a, b, kind):
     return corr
 
 
-@pytest.mark.parametrize("kind,Ci,Co", [("conv", 96, 192), ("convT", 384, 96)])
-def test_two_by_two_tap_weight_gradients_full_size(kind, Ci, Co):
-    """The direct row-split weight-gradient kernel on its 2x2-tap forms (Conv2d k4 s2 split into four kernel-parity
-    classes; the four parity classes of ConvTranspose2d k4 s2) at 8 x 512 x 1024: whole batch vs the sum of per-image
-    launches, and rank-one inputs vs their exact fp64 gradient."""
+@pytest.mark.parametrize("kind,Ci,Co,w32", [("conv", 96, 192, "1"), ("convT", 384, 96, "1"), ("conv", 96, 192, "2"), ("convT", 384, 96, "0")])
+def test_two_by_two_tap_weight_gradients_full_size(kind, Ci, Co, w32, monkeypatch):
+    """The weight gradients of the 2x2-tap forms (Conv2d k4 s2 split into four kernel-parity classes; the four parity
+    classes of ConvTranspose2d k4 s2) at 8 x 512 x 1024, on the kernels the default takes (direct row-split for the
+    former, F(3x3,2x2)-domain conv_wgrad32_kernel for the latter: ADH_WINO32_WGRAD=1) and with the choice forced the other
+    way: whole batch vs the sum of per-image launches, and rank-one inputs vs their exact fp64 gradient."""
+    monkeypatch.setenv("ADH_WINO32_WGRAD", w32)
     eng = _eng()
     if kind == "conv":
         xs, gs, wshape = (N, HH, WW, Ci), (N, HH // 2, WW // 2, Co), (Co, Ci, 4, 4)
