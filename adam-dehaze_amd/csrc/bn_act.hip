@@ -128,13 +128,18 @@ extern "C" int adh_bn_eval_bwd_vectors(void* stream, int C, int C4, const float*
 // four at a time (4-12 independent 16-byte loads in flight per lane: these kernels are HBM-bound).  The tensors are
 // far larger than L2 + Infinity Cache and each element is touched once per pass, so all of their loads / stores carry the
 // non-temporal hint (measured on 8 x 512 x 1024 x 96: bn_apply 0.632 -> 0.603 ms, bn_bwd_apply 1.30 -> 1.16-1.22 ms).
+#ifndef EW_UNROLL
 #define EW_UNROLL 8
+#endif
+#ifndef EW_MAXBLK
+#define EW_MAXBLK (256 * 8)
+#endif
 static int ew_blocks(int64_t P, int CQ) {
     int g = CQ, r = 256;   // gcd(CQ, 256)
     while (r) { const int t = g % r; g = r; r = t; }
     const int mult = CQ / g;                                  // blocks must be a multiple of this
     int64_t want = (P * CQ + 256 * EW_UNROLL - 1) / (256 * EW_UNROLL);
-    if (want > 256 * 8) want = 256 * 8;
+    if (want > EW_MAXBLK) want = EW_MAXBLK;
     int64_t blocks = (want + mult - 1) / mult * mult;
     if (blocks < mult) blocks = mult;
     return (int)blocks;
