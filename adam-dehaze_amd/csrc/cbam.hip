@@ -635,25 +635,49 @@ __global__ __launch_bounds__(256) void cbam_bwd_e_kernel(const float* __restrict
                                                          const float* __restrict__ gpool,
                                                          const int32_t* __restrict__ amax_idx, int HW, int C,
                                                          float* __restrict__ gx, int gx_cs) {
+    // thread = one channel quad for the whole launch (grid = a multiple of CQ / gcd(CQ, 256) blocks, cbam_scale_blocks): its
+    // per-channel constants are loaded once, and four pixels' loads are in flight per trip
     const int n = blockIdx.y;
     const int CQ = C / 4;
     const float invC = 1.0f / (float)C, invHW = 1.0f / (float)HW;
-    const int64_t total = (int64_t)HW * CQ;
+    const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t pstep = (int64_t)gridDim.x * 256 / CQ;
+    int64_t p = t / CQ;
+    const int c = (int)(t - p * CQ) * 4;
     const float* gn = g + (size_t)n * HW * g_cs;
     float* gxn = gx + (size_t)n * HW * gx_cs;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int p = (int)(idx / CQ);
-        const int c = (int)(idx - (int64_t)p * CQ) * 4;
-        const size_t pp = (size_t)n * HW + p;
-        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gn + (size_t)p * g_cs + c));
-        f32x4 r = cbam_gx1(gv, sa[pp], gsmap[pp * 2 + 0] * invC, gsmap[pp * 2 + 1], cidx[pp], c);
-        r = r * *reinterpret_cast<const f32x4*>(ca + (size_t)n * C + c) +
-            *reinterpret_cast<const f32x4*>(gpool + ((size_t)n * 2 + 0) * C + c) * invHW;
+    const f32x4 cav = *reinterpret_cast<const f32x4*>(ca + (size_t)n * C + c);
+    const f32x4 gavg = *reinterpret_cast<const f32x4*>(gpool + ((size_t)n * 2 + 0) * C + c) * invHW;
+    const f32x4 gmx = *reinterpret_cast<const f32x4*>(gpool + ((size_t)n * 2 + 1) * C + c);
+    int am[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (amax_idx[(size_t)n * C + c + j] == p) r[j] += gpool[((size_t)n * 2 + 1) * C + c + j];
-        __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(gxn + (size_t)p * gx_cs + c));
+    for (int j = 0; j < 4; ++j) am[j] = amax_idx[(size_t)n * C + c + j];
+    for (; p < HW; p += 4 * pstep) {
+        f32x4 gv[4];
+        float sv[4], gm[4], gxm[4];
+        int ci[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = p + u * pstep < HW ? p + u * pstep : p;
+            const size_t pp = (size_t)n * HW + q;
+            gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gn + (size_t)q * g_cs + c));
+            sv[u] = sa[pp];
+            gm[u] = gsmap[pp * 2 + 0];
+            gxm[u] = gsmap[pp * 2 + 1];
+            ci[u] = cidx[pp];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = p + u * pstep;
+            if (q < HW) {
+                f32x4 r = cbam_gx1(gv[u], sv[u], gm[u] * invC, gxm[u], ci[u], c);
+                r = r * cav + gavg;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (am[j] == (int)q) r[j] += gmx[j];
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(gxn + (size_t)q * gx_cs + c));
+            }
+        }
     }
 }
 
@@ -663,7 +687,7 @@ extern "C" int adh_cbam_bwd_e(void* stream, const float* g, int g_cs, const floa
     (void)x;
     (void)x_cs;
     if (!g || !ca || !sa || !gsmap || !cidx || !gpool || !amax_idx || !gx || C < 4 || (C & 3)) return ADH_E_ARG;
-    const int blocks = adh_min_i(adh_ceil_div((int64_t)HW * (C / 4), 256), 4096);
+    const int blocks = cbam_scale_blocks(HW, C / 4);
     hipLaunchKernelGGL(cbam_bwd_e_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, g, g_cs, ca, sa, gsmap, cidx,
                        gpool, amax_idx, HW, C, gx, gx_cs);
     return adh_check_launch();
