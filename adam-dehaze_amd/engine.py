@@ -799,7 +799,7 @@ class Engine:
                     gx = self._f(N, Hh, Ww, Cc)
                     H.call("adh_cbam_bwd_e", g.data_ptr(), g.stride(2), x.t.data_ptr(), x.cs, ca.data_ptr(),
                            sa.data_ptr(), gsmap.data_ptr(), cidx.data_ptr(), gpool.data_ptr(), amax_idx.data_ptr(), N,
-                           HW, Cc, gx.data_ptr(), gx.stride(2), work=3 * xbytes)
+                           HW, Cc, gx.data_ptr(), gx.stride(2), work=2 * xbytes)   # reads g, writes gx (x itself is not read)
                     self.accum(x, gx)
             self.tape.append(bwd)
         return o
