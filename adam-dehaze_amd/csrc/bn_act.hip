@@ -203,7 +203,12 @@ extern "C" int adh_bn_apply(void* stream, const float* y, int y_cs, const float*
 // ---------------------------------------------------------------------------------------------
 // backward pass 1: per-block sums of g and g*xhat
 // ---------------------------------------------------------------------------------------------
+#ifndef BNB_PPB
 #define BNB_PPB 2048  // pixels per block
+#endif
+#ifndef BNB_UNROLL
+#define BNB_UNROLL 4  // pixels per trip and thread (x 2 streams of 16-byte loads in flight)
+#endif
 
 extern "C" int adh_bn_bwd_num_blocks(int64_t P, int C) {
     (void)C;
@@ -236,11 +241,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         }
         const int64_t p0 = (int64_t)blockIdx.x * BNB_PPB;
         const int64_t p1 = p0 + BNB_PPB < P ? p0 + BNB_PPB : P;
-        for (int64_t p = p0 + prow; p < p1; p += 4 * R) {
-            f32x4 g[4], o[4], yy[4];
-            int mb[4];
+        for (int64_t p = p0 + prow; p < p1; p += BNB_UNROLL * R) {
+            f32x4 g[BNB_UNROLL], o[BNB_UNROLL], yy[BNB_UNROLL];
+            int mb[BNB_UNROLL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BNB_UNROLL; ++u) {
                 const int64_t q = p + u * R < p1 ? p + u * R : p;
                 g[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g_out + q * g_cs + c));
                 if (mask_bits) mb[u] = mask_bits[(q * CQ + cq) >> 1] >> (4 * (cq & 1));
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 yy[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + q * y_cs + c));
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BNB_UNROLL; ++u) {
                 if (p + u * R < p1) {
                     f32x4 gg = g[u];
                     if (mask_bits) {
