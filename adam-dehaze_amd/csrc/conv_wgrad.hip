@@ -227,6 +227,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const adh_conv_desc 
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
+#ifdef WR_PROF   // dev build (tools/prof_wino43.sh): per-workgroup s_memtime stamps of conv_wgrad_rows_kernel and the CU it ran on
+__device__ unsigned long long wr_prof_buf[16384 * 32];
+#define WR_STAMP(i) do { if (tid == 0 && bid < 16384) wr_prof_buf[bid * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int adh_wr_prof_read(void* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(wr_prof_buf), sizeof(wr_prof_buf)) == hipSuccess ? 0 : -1;
+}
+#else
+#define WR_STAMP(i) do {} while (0)
+#endif
+
 struct WrArgs {
     int ymin, xmin;            // input pixel of halo (0,0) for virtual pixel (0,0)
     int xps;                   // input pixels per halo pixel (in_s)
@@ -289,6 +299,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
     // XCD-aware decode: the `ngroups` workgroups that share one pixel range (and so its G tiles) get ids that
     // are congruent mod 8, i.e. land on one XCD and share its L2
     const int bid = blockIdx.x;
+    WR_STAMP(0);
+#ifdef WR_PROF
+    if (tid == 0 && bid < 16384) {
+        wr_prof_buf[bid * 32 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+        wr_prof_buf[bid * 32 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+    }
+#endif
     const int xcd = bid & 7;
     const int q = bid >> 3;
     const int grp = q % g.ngroups;
@@ -401,11 +418,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
     __builtin_amdgcn_s_barrier();
 
     int cur = 0;
+    WR_STAMP(1);
     for (int tile = t_begin; tile < t_end; ++tile) {
         int ntx = tx + 1, nty = ty, nn = n;
         if (ntx == g.tiles_x) { ntx = 0; ++nty; }
         if (nty == g.tiles_y) { nty = 0; ++nn; }
+        if (tile == t_begin + 1) WR_STAMP(8);
         if (tile + 1 < t_end) stage(nn, nty, ntx, cur ^ 1);
+        if (tile == t_begin + 1) WR_STAMP(9);
 
         if constexpr (!WINO) {
             const float* xl = smem + cur * BUF + (wave * WR_HP + h) * 32 + l31;
@@ -504,11 +524,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (tile == t_begin + 1) WR_STAMP(10);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (tile == t_begin + 1) WR_STAMP(11);
         __builtin_amdgcn_s_barrier();
+        if (tile == t_begin + 1) WR_STAMP(12);
         cur ^= 1;
         tx = ntx; ty = nty; n = nn;
     }
+    WR_STAMP(2);
 
     const int KP = d.Cin;
     if constexpr (WINO) {
@@ -542,6 +566,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(const adh_conv_
             }
         }
     }
+    WR_STAMP(3);
 }
 
 __host__ static int wgrad_geometry(const adh_conv_desc* d, ConvGeom* g, int TN, int xp) {

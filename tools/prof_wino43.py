@@ -20,14 +20,14 @@ def main():
     ap.add_argument("--cin", type=int, default=96)
     ap.add_argument("--h", type=int, default=512)
     ap.add_argument("--w", type=int, default=1024)
-    ap.add_argument("--kernel", default="w43", choices=["w43", "w32"])
+    ap.add_argument("--kernel", default="w43", choices=["w43", "w32", "wgw"], help="wgw: Winograd-domain weight gradient of the 3x3 layers")
     ap.add_argument("--case", default="down", choices=["down", "up"], help="w32: Conv2d k4 s2 96->192 / ConvTranspose2d k4 s2 384->96")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = H.load()
     Cc = args.cin
     eng = Engine(dev, record=False)
-    if args.kernel == "w43":
+    if args.kernel in ("w43", "wgw"):
         kind, k, stride, Cout = "conv", 3, 1, Cc
         x = Act(torch.randn(8, args.h, args.w, Cc, device=dev))
         w = (torch.randn(Cc, Cc, 3, 3, device=dev) * 0.05).requires_grad_(True)
@@ -41,9 +41,13 @@ def main():
         w = (torch.randn(Cc, Cout, 4, 4, device=dev) * 0.05).requires_grad_(True)
     o = eng.conv(x, w, None, None, kind=kind, k=k, stride=stride, pad=1, relu=False)
     out_t = o.t
+    gy = torch.randn_like(out_t)
 
     def run():
-        eng._run_gather(eng._launch_plan(kind, k, stride, 1, w, "fwd"), x, out_t, Cout, w)
+        if args.kernel == "wgw":
+            eng._wgrad(eng._launch_plan(kind, k, stride, 1, w, "fwd"), x, gy, Cout, w)
+        else:
+            eng._run_gather(eng._launch_plan(kind, k, stride, 1, w, "fwd"), x, out_t, Cout, w)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -54,7 +58,7 @@ def main():
     torch.cuda.synchronize()
     ev_us = e0.elapsed_time(e1) * 1000.0
     buf = np.zeros(16384 * 32, dtype=np.uint64)
-    rc = (lib.adh_w4_prof_read if args.kernel == "w43" else lib.adh_w3_prof_read)(C.c_void_p(buf.ctypes.data))
+    rc = {"w43": lib.adh_w4_prof_read, "w32": lib.adh_w3_prof_read, "wgw": lib.adh_wr_prof_read}[args.kernel](C.c_void_p(buf.ctypes.data))
     assert rc == 0
     b = buf.reshape(16384, 32)
     b = b[b[:, 0] != 0]
@@ -76,6 +80,8 @@ def main():
     chunk_rows = (("chunk 1: stage issue", 0, 1), ("transform", 1, 2), ("barrier", 2, 3), ("contraction", 3, 4), ("fix + barrier", 4, 5), ("whole chunk", 0, 5))
     if args.kernel == "w32":   # (a convT launch runs one class per launch: the event time covers the four launches, the stamps the last)
         chunk_rows = (("slab 1: contraction", 0, 1), ("fix + barrier", 1, 2), ("transform", 2, 3), ("barrier", 3, 4), ("whole slab", 0, 4))
+    if args.kernel == "wgw":   # (the event time also covers the split-sum and reduce kernels)
+        chunk_rows = (("tile 1: stage issue", 0, 1), ("16 k-steps", 1, 2), ("wait for the next tile's data", 2, 3), ("barrier", 3, 4), ("whole tile", 0, 4))
     for name, a, c in chunk_rows:
         dt = (tc[:, c] - tc[:, a]) * tick_us
         print(f"  {name:22s} mean {dt.mean():7.2f} us  p10 {np.percentile(dt, 10):7.2f}  p50 {np.percentile(dt, 50):7.2f}  p90 {np.percentile(dt, 90):7.2f}")
