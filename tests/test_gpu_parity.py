@@ -435,6 +435,8 @@ def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, algo, monkey
     ("convT", 2, 96, 32, 9, 50),       # transposed: four output-parity class descriptors with reversed taps, ragged
     ("convT", 1, 64, 96, 24, 48),      # exact regions
     ("convT", 1, 384, 96, 16, 64),     # the headline up-sampling layer's channels
+    ("convT", 2, 64, 48, 10, 40),      # transposed, partial last n-tile, ragged
+    ("convT", 1, 32, 8, 7, 30),        # transposed, a single partial n-tile
 ])
 def test_wino32_weight_gradient_matches_direct(kind, N, Ci, Co, Hh, Ww, monkeypatch):
     """F(3x3,2x2)-domain weight gradient of the 2x2-tap forms (conv_wgrad32_kernel + adh_wgrad_reduce_wino32) against the
