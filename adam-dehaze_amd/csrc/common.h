@@ -79,6 +79,9 @@ __device__ __forceinline__ void adh_mfma_operand_fence(float (&V)[4], float (&M)
                      "+v"(M[1][0]), "+v"(M[1][1]), "+v"(M[1][2]), "+v"(M[1][3]), "+v"(M[2][0]), "+v"(M[2][1]), "+v"(M[2][2]), "+v"(M[2][3]));
 }
 
+// conv_wgrad.hip: slab[0] = sum over `nsplit` partial slabs of n4 float4 each (in place, fixed order)
+void adh_wgrad_sum_splits(hipStream_t s, float* slab, int nsplit, int64_t n4);
+
 // conv_rows.hip: direct forward kernel for the 2x2 / 3x3-tap gather forms (0 blocks / ADH_E_UNSUPPORTED when `d`
 // is not one of its shapes; conv_igemm.hip then takes the launch)
 int adh_rows_fwd_num_blocks(const adh_conv_desc* d);

@@ -790,21 +790,37 @@ __global__ void wgrad_reduce_wino_kernel(const float* __restrict__ slab, int nsp
     }
 }
 
-// slab[0] = sum over splits (fixed order), 16 bytes per lane, eight independent loads in flight
+// slab[0] = sum over splits, in a fixed order (deterministic).  Block = 64 elements (16 bytes each) x 4 split groups: group y
+// adds splits y, y + 4, .. with eight independent loads in flight, the four partial sums meet in LDS.  (One thread per
+// element walking all the splits left the 96-channel layers -- 36,864 elements, 144 blocks -- latency-bound: 42 us.)
 __global__ __launch_bounds__(256) void wgrad_sum_splits_kernel(float* __restrict__ slab, int nsplit, int64_t n4) {
+    __shared__ f32x4 part[3][64];
     f32x4* s4 = reinterpret_cast<f32x4*>(slab);
-    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    for (int64_t i0 = blockIdx.x * (int64_t)64; i0 < n4; i0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = i0 + x;
         f32x4 a[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int sp = 0;
-        for (; sp + 8 <= nsplit; sp += 8) {
+        if (i < n4) {
+            int sp = y;
+            for (; sp + 28 < nsplit; sp += 32) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += s4[(int64_t)(sp + u) * n4 + i];
+                for (int u = 0; u < 8; ++u) a[u] += s4[(int64_t)(sp + 4 * u) * n4 + i];
+            }
+            for (; sp < nsplit; sp += 4) a[0] += s4[(int64_t)sp * n4 + i];
         }
-        for (; sp < nsplit; ++sp) a[0] += s4[(int64_t)sp * n4 + i];
-        s4[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        const f32x4 t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        if (y) part[y - 1][x] = t;
+        __syncthreads();
+        if (y == 0 && i < n4) s4[i] = ((t + part[0][x]) + (part[1][x] + part[2][x]));
+        __syncthreads();
     }
+}
+
+// shared by the other Winograd-domain reduce entry points (conv_wgrad32.hip, conv_wgrad43.hip)
+void adh_wgrad_sum_splits(hipStream_t s, float* slab, int nsplit, int64_t n4) {
+    hipLaunchKernelGGL(wgrad_sum_splits_kernel, dim3(adh_min_i(adh_ceil_div(n4, 64), 4096)), dim3(256), 0, s, slab, nsplit, n4);
 }
 
 extern "C" int adh_wgrad_reduce_wino(void* stream, float* slab, int nsplit, int KP, int NcP, const adh_wlayout* L,
@@ -814,8 +830,7 @@ extern "C" int adh_wgrad_reduce_wino(void* stream, float* slab, int nsplit, int 
     if (nsplit > 1) {
         // many splits x few (k, n) pairs would leave the transform kernel latency-bound: stream-sum the splits first
         const int64_t n4 = (int64_t)16 * KP * NcP / 4;
-        hipLaunchKernelGGL(wgrad_sum_splits_kernel, dim3(adh_min_i(adh_ceil_div(n4, 256), 2048)), dim3(256), 0, s, slab,
-                           nsplit, n4);
+        adh_wgrad_sum_splits(s, slab, nsplit, n4);
     }
     const int64_t total = (int64_t)L->K * L->Nc;
     hipLaunchKernelGGL(wgrad_reduce_wino_kernel, dim3(adh_min_i(adh_ceil_div(total, 64), 16384)), dim3(64), 0, s, slab, 1,

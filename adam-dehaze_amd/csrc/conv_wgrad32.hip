@@ -447,22 +447,6 @@ __global__ void wgrad_reduce_wino32_kernel(const float* __restrict__ slab, int n
     }
 }
 
-// slab[0] = sum over splits (fixed order), 16 bytes per lane, eight independent loads in flight
-__global__ __launch_bounds__(256) void wgrad32_sum_splits_kernel(float* __restrict__ slab, int nsplit, int64_t n4) {
-    f32x4* s4 = reinterpret_cast<f32x4*>(slab);
-    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 a[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int sp = 0;
-        for (; sp + 8 <= nsplit; sp += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += s4[(int64_t)(sp + u) * n4 + i];
-        }
-        for (; sp < nsplit; ++sp) a[0] += s4[(int64_t)sp * n4 + i];
-        s4[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
-}
 
 extern "C" int adh_wgrad_reduce_wino32(void* stream, float* slab, int nsplit, const adh_conv_desc* d, int KP, int NcP,
                                        const adh_wlayout* L, float* dst, int accumulate) {
@@ -479,7 +463,7 @@ extern "C" int adh_wgrad_reduce_wino32(void* stream, float* slab, int nsplit, co
     hipStream_t s = (hipStream_t)stream;
     if (nsplit > 1) {
         const int64_t n4 = (int64_t)p.ncls * 16 * KP * NcP / 4;
-        hipLaunchKernelGGL(wgrad32_sum_splits_kernel, dim3(adh_min_i(adh_ceil_div(n4, 256), 2048)), dim3(256), 0, s, slab, nsplit, n4);
+        adh_wgrad_sum_splits(s, slab, nsplit, n4);
     }
     const int64_t total = (int64_t)p.ncls * L->K * L->Nc;
     hipLaunchKernelGGL(wgrad_reduce_wino32_kernel, dim3(adh_min_i(adh_ceil_div(total, 64), 16384)), dim3(64), 0, s, slab, 1, KP,

@@ -454,30 +454,13 @@ __global__ void wgrad_reduce_wino43_kernel(const float* __restrict__ slab, int K
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad43_sum_splits_kernel(float* __restrict__ slab, int nsplit, int64_t n4) {
-    f32x4* s4 = reinterpret_cast<f32x4*>(slab);
-    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 a[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int sp = 0;
-        for (; sp + 8 <= nsplit; sp += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += s4[(int64_t)(sp + u) * n4 + i];
-        }
-        for (; sp < nsplit; ++sp) a[0] += s4[(int64_t)sp * n4 + i];
-        s4[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
-}
-
 extern "C" int adh_wgrad_reduce_wino43(void* stream, float* slab, int nsplit, int KP, int NcP, const adh_wlayout* L,
                                        float* dst, int accumulate) {
     if (!slab || !L || !dst || nsplit < 1 || L->KHt != 3 || L->KWt != 3 || (NcP & 3)) return ADH_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (nsplit > 1) {
         const int64_t n4 = (int64_t)36 * KP * NcP / 4;
-        hipLaunchKernelGGL(wgrad43_sum_splits_kernel, dim3(adh_min_i(adh_ceil_div(n4, 256), 2048)), dim3(256), 0, s, slab, nsplit,
-                           n4);
+        adh_wgrad_sum_splits(s, slab, nsplit, n4);
     }
     const int64_t total = (int64_t)L->K * L->Nc;
     hipLaunchKernelGGL(wgrad_reduce_wino43_kernel, dim3(adh_min_i(adh_ceil_div(total, 64), 16384)), dim3(64), 0, s, slab, KP, NcP,
