@@ -75,6 +75,87 @@ def test_joint_step_composition_vs_oracle():
         assert rel_err(dict(models[n].named_parameters())[name].grad, sds[n][name].grad) < 2e-2, n
 
 
+def test_joint_step_gradients_kink_matched():
+    """T1 (train_joint.py:129-166) on the kink-matched gate: classifier (eval: its dropout is
+    RNG-dependent in the reference's train mode) -> SoftRouter(T = 0.5) over the three train-mode branches -> the FULL
+    JointLoss (L1 + 0.1 VGG16-content + 0.1 LPIPS + 0.2 CE) -> backward.  EVERY parameter of the three branches and of
+    the classifier head against the float64 oracle that replays the ReLU masks the branch kernels used (tests/_util.py):
+    err_gpu <= 5e-4 of the tensor's scale.  The loss networks' and the backbone's own ReLUs / max-pools run free in the
+    oracle (their masks are not replayable through max-pooling); the table goes to gpurun_out/grad_gate_joint.txt."""
+    import os
+    torch.manual_seed(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        system = T.build_joint_system(_cfg())
+    clf, models, router, crit = system["classifier"], system["models"], system["router"], system["criterion"]
+    sd_clf0 = {k: v.detach().cpu().clone() for k, v in clf.state_dict().items()}
+    sds0 = {n: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for n, m in models.items()}
+    vgg0 = {k: v.detach().cpu() for k, v in crit.dehazing_loss.content_loss.state_dict().items()}
+    lp0 = {k: v.detach().cpu() for k, v in crit.dehazing_loss.perceptual_loss.state_dict().items()}
+    batch = next(T.synthetic_loader(4, 32, 1, seed=3, device=DEV))
+    hazy, clear, labels = batch["hazy"].cpu(), batch["clear"].cpu(), batch["intensity"].cpu()
+    fns = {"low": R.lightweight_forward, "medium": R.medium_forward, "high": R.high_forward}
+
+    def oracle(dtype, masks=None):
+        def cast(sd, grad=True):
+            out = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+            for k, v in out.items():
+                if grad and v.is_floating_point() and "running" not in k:
+                    v.requires_grad_(True)
+            return out
+        sd_clf, sds = cast(sd_clf0), {n: cast(sd) for n, sd in sds0.items()}
+        logits, _ = R.classifier_forward(hazy.to(dtype), sd_clf, "resnet18")
+        outs = {}
+        for n in fns:
+            def run(n=n):
+                return fns[n](hazy.to(dtype), sds[n], training=True)
+            outs[n] = oracle_with_masks(run, masks[n]) if masks is not None else run()
+        blended, _ = R.soft_route(outs, logits, 0.5)
+        total, _ = R.joint_loss(blended, clear.to(dtype), logits, labels, cast(vgg0, False), cast(lp0, False))
+        total.backward()
+        return float(total), sd_clf, sds
+
+    clf.eval()
+    for m in models.values():
+        m.train()
+    with kink_matched(router) as km:
+        logits, _ = clf(hazy.to(DEV))
+        dehazed, _ = router(hazy.to(DEV), logits)
+        total, _ = crit(dehazed, clear.to(DEV), logits, labels.to(DEV))
+        total.backward()
+    torch.cuda.synchronize()
+    allm = km.masks()
+    masks = {n: {k[len("models.%s." % n):]: v for k, v in allm.items() if k.startswith("models.%s." % n)} for n in fns}
+    assert all(len(masks[n]) >= 5 for n in fns)
+    tot32, clf32, sds32 = oracle(torch.float32)
+    tot64, clf64, sds64 = oracle(torch.float64, masks)
+    assert abs(float(total) - tot64) < 1e-4 * max(1.0, abs(tot64))
+    bad, lines = [], []
+
+    def check(tag, name, g, g64, g32):
+        scale = max(float(g64.abs().max()), 1e-6)
+        err_gpu = float((g.cpu().double() - g64).abs().max()) / scale
+        err_cpu = float((g32.double() - g64).abs().max()) / scale
+        lines.append(f"joint {tag:7s} {name:44s} scale {scale:.2e}  err_gpu {err_gpu:.2e}  (fp32 CPU oracle, free kinks: {err_cpu:.2e})")
+        if not err_gpu <= 5e-4:
+            bad.append((tag, name, err_gpu, err_cpu))
+    for n, m in models.items():
+        for name, p in m.named_parameters():
+            if name.startswith("decoder") and name.endswith(".0.bias"):
+                continue   # ConvTranspose bias feeding train-mode BN: the true gradient is exactly 0
+            check(n, name, p.grad, sds64[n][name].grad, sds32[n][name].grad)
+    for name, p in clf.named_parameters():
+        if name.startswith("classifier."):
+            check("clfhead", name, p.grad, clf64[name].grad, clf32[name].grad)
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "grad_gate_joint.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    assert not bad, bad[:8]
+
+
 def test_joint_training_runs_and_uses_duplicate_param_adam():
     torch.manual_seed(2)
     with warnings.catch_warnings():

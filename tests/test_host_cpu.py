@@ -215,6 +215,149 @@ def test_counted_wait_kernels_have_no_scratch_traffic(tmp_path):
     assert nstores >= 100
 
 
+_ISA_CACHE = {}
+
+
+def _isa_lines(fn, tmpdir):
+    """Instruction lines (mnemonic + operands, labels kept as 'label:') of csrc/<fn> compiled to gfx950 ISA on the host."""
+    import shutil
+    import subprocess
+    if fn in _ISA_CACHE:
+        return _ISA_CACHE[fn]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "adam-dehaze_amd", "csrc", fn)
+    out = os.path.join(str(tmpdir), fn + ".hz.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, timeout=900)
+    code = []
+    for ln in open(out).read().splitlines():
+        t = ln.strip()
+        if not t or t.startswith((";", ".", "//")):
+            continue
+        t = t.split(";")[0].split("//")[0].strip()
+        if ln.startswith("\t"):
+            code.append(t)
+        elif t.endswith(":"):
+            code.append(t)
+    _ISA_CACHE[fn] = code
+    return code
+
+
+def _regs(tok):
+    """'v12' / 'v[4:7]' / 'a[0:15]' / 'a3' -> {('v', 12)} ... ; anything else -> empty set."""
+    tok = tok.strip().rstrip(",")
+    m = re.match(r"^([va])(\d+)$", tok)
+    if m:
+        return {(m.group(1), int(m.group(2)))}
+    m = re.match(r"^([va])\[(\d+):(\d+)\]$", tok)
+    if m:
+        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    return set()
+
+
+MFMA_ASM_FILES = ("conv_rows.hip", "conv_wgrad.hip", "conv_wgrad43.hip", "conv_wgrad32.hip", "conv_wino.hip", "conv_wino43.hip",
+                  "conv_igemm.hip")
+
+
+@pytest.mark.parametrize("fn", MFMA_ASM_FILES)
+def test_no_valu_write_within_two_wait_states_of_an_mfma_operand_read(fn, tmp_path_factory):
+    """gfx950 VALU -> MFMA operand hazard (csrc/common.h adh_mfma_operand_fence): an MFMA
+    that reads a VGPR as srcA / srcB which a VALU instruction wrote one or two instructions earlier gets the OLD value.
+    hipcc pads this for MFMA instructions it emits itself; the inline-asm MFMAs of the six kernel files (twelve asm
+    strings: the AGPR- and VGPR-accumulator form of `mfma_pinned` in each) are outside its hazard recogniser, and only
+    two of them carry an `s_nop 1` of their own -- the others rely on their operands coming straight from LDS / global
+    loads.  This walks the ISA of every kernel in those files: for each v_mfma_*, no VALU instruction among the
+    instructions that precede it by fewer than two wait states (s_nop N = N + 1 wait states) may write a register of
+    srcA or srcB; a VALU write of srcC (accumulator in VGPRs, or v_accvgpr_write into its AGPRs) is held to the same
+    distance.  Branch targets inside the window are walked through as fall-through code (conservative for the loops
+    these kernels have: the back edge's predecessor is the loop's last instruction, checked as a separate window
+    below)."""
+    code = _isa_lines(fn, tmp_path_factory.getbasetemp())
+    nmfma = 0
+    labels = {ln[:-1]: i for i, ln in enumerate(code) if ln.endswith(":")}
+
+    def valu_writes(ln):
+        t = ln.split(None, 1)
+        op = t[0]
+        if not op.startswith("v_") or op.startswith(("v_mfma", "v_smfmac", "v_cmp", "v_readlane", "v_readfirstlane", "v_nop")):
+            return set()
+        if len(t) < 2:
+            return set()
+        return _regs(t[1].split(",")[0])
+
+    def check_window(k, preds, what):
+        """preds: instruction indices in reverse program order that lead to the MFMA at k."""
+        ops = [o.strip() for o in code[k].split(None, 1)[1].split(",")]
+        srcs = _regs(ops[1]) | _regs(ops[2]) | _regs(ops[3].split()[0])
+        waited = 0
+        for j in preds:
+            ln = code[j]
+            if ln.endswith(":"):
+                continue
+            t = ln.split()
+            if t[0] == "s_nop":
+                waited += int(t[1]) + 1
+            else:
+                if waited >= 2:
+                    break
+                hit = valu_writes(ln) & srcs
+                assert not hit, (fn, what, j, ln, k, code[k], sorted(hit))
+                waited += 1
+            if waited >= 2:
+                break
+
+    # back edges: for `s_cbranch* label` / `s_branch label` at index b, the instructions before b precede label's code too
+    back = {}
+    for b, ln in enumerate(code):
+        t = ln.split()
+        if t and t[0].startswith(("s_cbranch", "s_branch")) and t[-1] in labels:
+            back.setdefault(labels[t[-1]], []).append(b)
+    for k, ln in enumerate(code):
+        if not ln.startswith("v_mfma"):
+            continue
+        nmfma += 1
+        check_window(k, range(k - 1, max(k - 8, -1), -1), "fall-through")
+        # if a label sits within the two instructions before the MFMA, also walk each branch that jumps to it
+        for j in range(k - 1, max(k - 4, -1), -1):
+            if code[j].endswith(":"):
+                between = list(range(k - 1, j, -1))
+                for b in back.get(j, []):
+                    check_window(k, between + list(range(b - 1, max(b - 8, -1), -1)), "via branch at %d" % b)
+    assert nmfma >= (8 if fn != "conv_igemm.hip" else 4), (fn, nmfma)
+
+
+def test_mfma_hazard_walker_flags_a_planted_violation():
+    """The walker above must actually see the pattern it guards against (and accept it once padded)."""
+    ok = ["v_fmac_f32_e32 v5, v1, v2", "s_nop 1", "v_mfma_f32_32x32x2_f32 a[0:15], v5, v6, a[0:15]"]
+    bad1 = ["v_fmac_f32_e32 v5, v1, v2", "v_mfma_f32_32x32x2_f32 a[0:15], v5, v6, a[0:15]"]
+    bad2 = ["v_pk_fma_f32 v[6:7], v[0:1], v[2:3], v[8:9]", "ds_read_b32 v9, v10", "v_mfma_f32_32x32x2_f32 a[0:15], v5, v6, a[0:15]"]
+    fine = ["v_pk_fma_f32 v[6:7], v[0:1], v[2:3], v[8:9]", "ds_read_b32 v9, v10", "s_nop 0",
+            "v_mfma_f32_32x32x2_f32 a[0:15], v5, v6, a[0:15]"]
+    accw = ["v_accvgpr_write_b32 a3, v1", "v_mfma_f32_32x32x2_f32 a[0:15], v5, v6, a[0:15]"]
+    import tests.test_host_cpu as me
+    for name, prog, want_ok in (("ok", ok, True), ("bad1", bad1, False), ("bad2", bad2, False), ("fine", fine, True),
+                                ("accw", accw, False)):
+        me._ISA_CACHE["__planted__.hip"] = prog + ["v_mfma_f32_32x32x2_f32 a[16:31], v50, v60, a[16:31]"] * 8
+        try:
+            _run_walker("__planted__.hip")
+            passed = True
+        except AssertionError:
+            passed = False
+        finally:
+            del me._ISA_CACHE["__planted__.hip"]
+        assert passed == want_ok, name
+
+
+def _run_walker(fn):
+    class _F:
+        @staticmethod
+        def getbasetemp():
+            return "/tmp"
+    test_no_valu_write_within_two_wait_states_of_an_mfma_operand_read(fn, _F)
+
+
 def test_adam_state_dict_layout_matches_torch():
     """optim.Adam.state_dict() uses torch.optim.Adam's layout (duplicates under the index of their last occurrence,
     as recorded from torch in adam_dup_foreach.npz) and round-trips through torch.optim.Adam.load_state_dict."""

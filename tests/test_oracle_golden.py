@@ -6,6 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import adam_dehaze_amd as A
 from oracle import ref_cpu as R
 from tests._util import load_golden, sub_sd, t, max_abs, rel_err
 
@@ -251,3 +252,25 @@ def test_fog_restatement_properties():
     f = R.apply_fog(torch.zeros(1, 3, 21, 41), [1.0], [1.0])[0, 0]
     yy, xx = np.unravel_index(int(f.argmin()), f.shape)
     assert (yy, xx) == (4, 20)     # y = 0.2 * 20, x = 0.5 * 40
+
+
+FULLWIDTH = [("light", R.lightweight_forward, lambda: A.LightweightDehazeModel(base_channels=32, n_blocks=3)),
+             ("medium", R.medium_forward, lambda: A.MediumIntensityDehazeModel(base_channels=64)),
+             ("high", R.high_forward, lambda: A.HighIntensityDehazeModel(base_channels=96))]
+
+
+@pytest.mark.parametrize("name,fwd,ctor", FULLWIDTH, ids=[c[0] for c in FULLWIDTH])
+def test_fullwidth_default_models_vs_reference_held_outputs(name, fwd, ctor):
+    """BASELINE config 1: the DEFAULT full-width Light / Medium / Complex (low_intensity.py:33-45,
+    medium_intensity.py:78-117, high_intensity.py:92-138) at 1x3x256x256, seed 42, eval mode.  The reference computed
+    `out_patch`, `out_mean`, `out_absmax` (tools/gen_golden.py section (v)); the oracle must reproduce them from the
+    seeded constructor (whose parameters are SHA-256-identical to the reference's, tests/test_host_cpu.py)."""
+    rec = load_golden("fullwidth_summaries")
+    torch.manual_seed(42)
+    sd = {k: v.detach().clone() for k, v in ctor().state_dict().items()}
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(42))
+    with torch.no_grad():
+        out = fwd(x, sd, training=False)
+    assert max_abs(out[0, :, 100:108, 100:108], rec[name + ".out_patch"]) < TOL
+    assert abs(float(out.double().mean()) - float(rec[name + ".out_mean"])) < 1e-7
+    assert abs(float(out.abs().max()) - float(rec[name + ".out_absmax"])) < TOL
