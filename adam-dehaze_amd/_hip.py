@@ -147,7 +147,7 @@ _SIGNATURES = {
     "adh_rows_sum": [vp, vp, i32, i32, f32, vp, i32],
     "adh_adam_step": [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32],
     "adh_adam_chunk_elems": [],
-    "adh_adam_multi": [vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, i32, i32],
+    "adh_adam_multi": [vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, i32, i32, i32],
     "adh_apply_fog": [vp, vp, vp, vp, i32, i32, i32, vp],
     "adh_psnr_num_blocks": [i64],
     "adh_psnr": [vp, vp, vp, i32, i64, f32, vp, i32, vp, vp],

@@ -40,9 +40,11 @@ __device__ __forceinline__ void adam_elem(float& pv, float gv0, float& mv, float
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(const adh_adam_tensor* __restrict__ table,
                                                          const int32_t* __restrict__ chunks, float lr, float beta1,
-                                                         float beta2, float eps, float wd, float gscale, int dup_mode) {
+                                                         float beta2, float eps, float wd, float gscale, int dup_mode,
+                                                         int calls_since_upload) {
     const int ti = chunks[2 * blockIdx.x], ci = chunks[2 * blockIdx.x + 1];
-    const adh_adam_tensor t = table[ti];
+    adh_adam_tensor t = table[ti];
+    t.step += calls_since_upload * t.repeats;   // the table stays resident: every call advances a tensor by `repeats`
     const int64_t base = (int64_t)ci * ADAM_CHUNK;
     const int n = (int)((t.n - base) < ADAM_CHUNK ? (t.n - base) : ADAM_CHUNK);
     float* __restrict__ p = t.p + base;
@@ -83,12 +85,12 @@ extern "C" int adh_adam_chunk_elems(void) { return ADAM_CHUNK; }
 
 extern "C" int adh_adam_multi(void* stream, const adh_adam_tensor* table_dev, const int32_t* chunks_dev, int nchunks, float lr,
                               float beta1, float beta2, float eps, float weight_decay, float grad_scale, int dup_mode,
-                              int max_repeats) {
+                              int max_repeats, int calls_since_upload) {
     if (!table_dev || !chunks_dev || nchunks < 1 || max_repeats < 1 || max_repeats > ADAM_MAX_REPEATS ||
-        (dup_mode != 0 && dup_mode != 1))
+        (dup_mode != 0 && dup_mode != 1) || calls_since_upload < 0)
         return ADH_E_ARG;
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table_dev, chunks_dev, lr, beta1,
-                       beta2, eps, weight_decay, grad_scale, dup_mode);
+                       beta2, eps, weight_decay, grad_scale, dup_mode, calls_since_upload);
     return adh_check_launch();
 }
 

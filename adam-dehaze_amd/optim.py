@@ -57,6 +57,8 @@ class Adam:
         self._table_dev = None
         self._chunks_dev = None
         self._nchunks = 0
+        self._calls_since_upload = 0
+        self._table_host = None
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -85,24 +87,38 @@ class Adam:
         if not live:
             return
         dev = live[0][0].device
-        # pointer table (48 B per tensor; the step counters advance every call, so it is rebuilt and uploaded per step:
-        # ~15 KB for the joint model); the (tensor, chunk) list only depends on the live set
-        chunk = H.value("adh_adam_chunk_elems")
-        table = (H.AdamTensor * len(live))()
-        for i, (p, g, st) in enumerate(live):
-            t = table[i]
-            t.p, t.g, t.m, t.v = p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr()
-            t.n, t.step, t.repeats = p.numel(), st["step"], self.repeats[id(p)]
-        self._table_dev = torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(dev)
-        key = tuple(p.numel() for p, _, _ in live)
+        # The pointer table (48 B per tensor, ~15 KB for the joint model) and the (tensor, chunk) list live on the device
+        # and are uploaded only when a pointer or the live set changes (a per-step pageable upload made every
+        # optimiser step a host-device sync).  The step counters advance on the device side of the ABI: the kernel adds
+        # `calls_since_upload * repeats` to the uploaded value.  An upload goes through a pinned staging buffer and is
+        # asynchronous on the current stream.
+        since = self._calls_since_upload
+        key = tuple((p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), self.repeats[id(p)],
+                     st["step"] - since * self.repeats[id(p)])        # the step the resident table was uploaded with
+                    for p, g, st in live)
         if key != self._table_key:
-            chunks = [(i, c) for i, (p, _, _) in enumerate(live) for c in range((p.numel() + chunk - 1) // chunk)]
-            self._chunks_dev = torch.tensor(chunks, dtype=torch.int32).reshape(-1).to(dev)
-            self._nchunks = len(chunks)
-            self._table_key = key
+            chunk = H.value("adh_adam_chunk_elems")
+            table = (H.AdamTensor * len(live))()
+            for i, (p, g, st) in enumerate(live):
+                t = table[i]
+                t.p, t.g, t.m, t.v = p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr()
+                t.n, t.step, t.repeats = p.numel(), st["step"], self.repeats[id(p)]
+            chunks = np.array([(i, c) for i, (p, _, _) in enumerate(live) for c in range((p.numel() + chunk - 1) // chunk)],
+                              dtype=np.int32).reshape(-1)
+            raw = np.frombuffer(bytes(table), dtype=np.uint8)
+            host = torch.empty(raw.size + chunks.size * 4, dtype=torch.uint8).pin_memory()
+            host[:raw.size].copy_(torch.from_numpy(raw.copy()))
+            host[raw.size:].copy_(torch.from_numpy(chunks.view(np.uint8).copy()))
+            both = host.to(dev, non_blocking=True)
+            self._table_host = host                      # keep the staging buffer alive until the copy has run
+            self._table_dev, self._chunks_dev = both[:raw.size], both[raw.size:]
+            self._nchunks = chunks.size // 2
+            self._calls_since_upload = 0
+            self._table_key = tuple(k[:6] + (st["step"],) for k, (_, _, st) in zip(key, live))
         H.call("adh_adam_multi", self._table_dev.data_ptr(), self._chunks_dev.data_ptr(), self._nchunks, lr, self.betas[0],
                self.betas[1], self.eps, self.weight_decay, self.grad_scale, 1 if self.duplicates == "foreach" else 0,
-               max(self.repeats[id(p)] for p, _, _ in live))
+               max(self.repeats[id(p)] for p, _, _ in live), self._calls_since_upload)
+        self._calls_since_upload += 1
         for p, _, st in live:
             st["step"] += self.repeats[id(p)]
         from .engine import invalidate_weight_cache   # the kernel wrote the parameters behind torch's version counter

@@ -2,8 +2,12 @@
 backend on ROCm) over xGMI.
 
 The reference is single-device (config.yaml:85); sharding the batch by image is the build's
-addition.  Every rank holds a full replica; BatchNorm statistics stay per replica
-("replica-BN", exactly PyTorch-DDP semantics).  The only collective on the data path is the gradient
+addition.  Every rank holds a full replica; BatchNorm batch statistics stay per replica
+("replica-BN": the forward / backward arithmetic of PyTorch DDP without SyncBatchNorm).  Unlike DDP's default
+`broadcast_buffers=True` the running statistics are NOT re-synchronised every forward pass: they drift apart between
+the replicas during an epoch, and `broadcast_buffers()` (rank 0's values) is called before validation and before rank 0
+writes a checkpoint (train.py).  `sync_bn=True` (SyncBatchNorm, SURVEY 8e mode ii) is the opt-in that reproduces the
+single-process reference at the global batch.  The only collective on the data path is the gradient
 all-reduce, organised for MI355X's point-to-point xGMI (7 links x ~153 GB/s per GPU, ring collectives are
 per-link bound): the whole model is 65-140 MB, so it travels as a handful of large flat buckets.
 
@@ -22,6 +26,11 @@ per-link bound): the whole model is 65-140 MB, so it travels as a handful of lar
   has-gradient bitmap (MAX) so that parameters no rank produced keep `grad = None` -- Adam then skips
   them exactly as the single-process reference does -- at the cost of one small D2H read per step;
   with `detect_unused=False` every parameter ends with a (possibly zero) gradient.
+
+STATUS: the `nccl` (= RCCL) branches of this file -- ReduceOp.AVG, asynchronous bucket all-reduces launched from inside
+Engine.backward() onto RCCL's stream -- have NOT run on hardware: no multi-GPU node was available to this build; all
+rehearsal is gloo (CPU tensors, and GPU tensors on one MI355X), which takes the SUM + scale branch.  The overlap claims
+are therefore by construction, not measured.
 
 Works with the gloo backend as well (CPU tensors in the world-size-2 tests here; GPU tensors for a
 two-process rehearsal on one MI355X): gloo has no AVG, so SUM is followed by one in-place scale.
@@ -220,6 +229,22 @@ class GradientSynchronizer:
                     dist.broadcast(t.data, src=src)
         from .engine import invalidate_weight_cache
         invalidate_weight_cache()
+
+
+def _broadcast_buffers(self, *modules: torch.nn.Module, src: int = 0):
+    """Every rank takes rank `src`'s buffers (BatchNorm running statistics, num_batches_tracked)."""
+    if self.world <= 1:
+        return
+    with torch.no_grad():
+        seen = set()
+        for m in modules:
+            for t in m.buffers():
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    dist.broadcast(t.data, src=src)
+
+
+GradientSynchronizer.broadcast_buffers = _broadcast_buffers
 
 
 def all_reduce_mean_scalar(value: float, device=None) -> float:

@@ -213,9 +213,10 @@ def validate_joint(system: Dict, val_loader: Iterable[Dict]) -> Dict[str, float]
             add("val_psnr", psnr_batch(dehazed, clear).double().sum())
             add("val_ssim", ssim_batch(dehazed, clear).double().sum())
             count += n
-    if not sums:
-        return {"val_loss": 0.0, "val_dehaze_loss": 0.0, "val_class_loss": 0.0, "val_psnr": 0.0, "val_ssim": 0.0,
-                "val_samples": 0}
+    # fixed key set, zeros when this rank saw nothing: under data parallelism EVERY rank must enter the all-reduce inside
+    # _finish_validation (a rank returning early here left the others waiting in the collective)
+    for k in ("val_loss", "val_dehaze_loss", "val_class_loss", "val_psnr", "val_ssim"):
+        sums.setdefault(k, torch.zeros((), dtype=torch.float64, device=dev))
     return _finish_validation(sums, count, dev)
 
 
@@ -246,8 +247,8 @@ def validate_dehazing(model, criterion, val_loader: Iterable[Dict], level: Optio
             add("val_psnr", psnr_batch(out, clear).double().sum())
             add("val_ssim", ssim_batch(out, clear).double().sum())
             count += n
-    if not sums:
-        return {"val_loss": 0.0, "val_perceptual": 0.0, "val_psnr": 0.0, "val_ssim": 0.0, "val_samples": 0}
+    for k in ("val_loss", "val_perceptual", "val_psnr", "val_ssim"):      # see validate_joint: no early return
+        sums.setdefault(k, torch.zeros((), dtype=torch.float64, device=torch.device(device)))
     return _finish_validation(sums, count, torch.device(device))
 
 
@@ -272,6 +273,32 @@ def dehazing_checkpoint(model, optimizer, scheduler, epoch: int, val: Dict[str, 
     return {"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
             "val_psnr": val["val_psnr"], "val_ssim": val["val_ssim"], "val_loss": val["val_loss"],
             "scheduler_state_dict": scheduler.state_dict()}
+
+
+def save_checkpoint_atomic(obj: Dict, path: str) -> None:
+    """torch.save to `<path>.tmp.<pid>` + os.replace: a reader (another rank's load_pretrained_model, a --resume) never
+    sees a half-written zip."""
+    tmp = f"{path}.tmp.{os.getpid()}"
+    try:
+        torch.save(obj, tmp)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
+def _barrier():
+    """All ranks wait here (after rank 0's checkpoint block, before anyone reads what it wrote)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def _sync_buffers_from_rank0(sync, *modules) -> None:
+    """Replica-BN lets the BatchNorm running statistics of the replicas drift apart; before validation and before rank 0
+    writes a checkpoint every rank takes rank 0's buffers (what DDP's broadcast_buffers=True does every forward)."""
+    if sync is not None and sync.world > 1:
+        sync.broadcast_buffers(*modules)
 
 
 def find_resume_checkpoint(checkpoint_dir: str) -> Optional[str]:
@@ -313,9 +340,29 @@ def _resolve_resume(resume, checkpoint_dir: str) -> Optional[str]:
     return path
 
 
+def checkpoint_stage(path: str, config) -> str:
+    """Which training stage wrote `path`: 'joint' (train_joint.py:272-283 key set) or the branch level 'low' / 'medium' /
+    'high' whose state_dict key set the checkpoint's `model_state_dict` has (train_dehazing.py:196-203).  Raises
+    ValueError for anything else.  main.py uses it to hand an explicit `--resume <file>` to the one stage it belongs to."""
+    ck = torch.load(path, map_location="cpu")
+    if "router_state_dict" in ck:
+        return "joint"
+    if "model_state_dict" not in ck:
+        raise ValueError(f"--resume {path}: neither a joint nor a branch checkpoint (keys {sorted(ck)[:6]} ...)")
+    keys = set(ck["model_state_dict"])
+    for level, factory in (("low", create_low_intensity_model), ("medium", create_medium_intensity_model),
+                           ("high", create_high_intensity_model)):
+        if set(factory(config).state_dict()) == keys:
+            return level
+    raise ValueError(f"--resume {path}: model_state_dict matches none of the configured branches")
+
+
 def resume_joint(system: Dict, path: str) -> int:
     """Restore a joint checkpoint; returns the epoch to continue with."""
     ck = torch.load(path, map_location="cpu")
+    if "router_state_dict" not in ck:
+        raise ValueError(f"--resume {path}: not a joint-training checkpoint (keys {sorted(ck)[:6]} ...); a branch "
+                         "checkpoint resumes `--mode train_dehazing`, not this stage")
     system["router"].load_state_dict(ck["router_state_dict"])   # holds the classifier and the three branches
     if "optimizer_state_dict" in ck:
         system["optimizer"].load_state_dict(ck["optimizer_state_dict"])
@@ -377,6 +424,7 @@ def train_joint_model(config, train_loader=None, val_loader=None, steps_per_epoc
             stats = joint_train_step(system, batch)
             total = stats["loss"] if total is None else total + stats["loss"]
             n += 1
+        _sync_buffers_from_rank0(system["sync"], system["router"])
         val = validate_joint(system, loader_for(val_loader, 0, val_steps, 500000))   # a fixed validation set
         train_loss = all_reduce_mean_scalar(float(total) / max(1, n) if total is not None else 0.0, dev)
         system["scheduler"].step(val["val_loss"])      # every rank steps on the same (rank-averaged) value
@@ -387,11 +435,13 @@ def train_joint_model(config, train_loader=None, val_loader=None, steps_per_epoc
                   f"(Dehaze: {val['val_dehaze_loss']:.4f}, Class: {val['val_class_loss']:.4f})\n"
                   f"  Val PSNR: {val['val_psnr']:.2f} dB, Val SSIM: {val['val_ssim']:.4f}")
             if val["val_psnr"] > best_val_psnr:
-                torch.save(joint_checkpoint(system, epoch, val), os.path.join(ck_dir, "best_model.pth"))
+                save_checkpoint_atomic(joint_checkpoint(system, epoch, val), os.path.join(ck_dir, "best_model.pth"))
                 print(f"Saved best model with validation PSNR: {val['val_psnr']:.2f} dB")
             if (epoch + 1) % 5 == 0:
-                torch.save(joint_checkpoint(system, epoch, val), os.path.join(ck_dir, f"checkpoint_epoch_{epoch + 1}.pth"))
+                save_checkpoint_atomic(joint_checkpoint(system, epoch, val),
+                                       os.path.join(ck_dir, f"checkpoint_epoch_{epoch + 1}.pth"))
         best_val_psnr = max(best_val_psnr, val["val_psnr"])
+        _barrier()       # nobody runs ahead (and reads a checkpoint) while rank 0 is still writing
     return system, history
 
 
@@ -419,6 +469,13 @@ def train_dehazing_model(config, intensity_level: str, train_loader=None, val_lo
     path = _resolve_resume(resume, ck_dir)
     if path is not None:
         ck = torch.load(path, map_location="cpu")
+        if "model_state_dict" not in ck:
+            raise ValueError(f"--resume {path}: not a branch checkpoint (keys {sorted(ck)[:6]} ...); a joint checkpoint "
+                             "resumes `--mode train_joint`")
+        missing = set(model.state_dict()) ^ set(ck["model_state_dict"])
+        if missing:
+            raise ValueError(f"--resume {path}: checkpoint does not belong to the '{intensity_level}' branch "
+                             f"({len(missing)} state_dict keys differ, e.g. {sorted(missing)[:3]})")
         model.load_state_dict(ck["model_state_dict"])
         if "optimizer_state_dict" in ck:
             optimizer.load_state_dict(ck["optimizer_state_dict"])
@@ -448,19 +505,21 @@ def train_dehazing_model(config, intensity_level: str, train_loader=None, val_lo
                 st = dehazing_train_step(model, criterion, optimizer, batch, level, device, sync=sync)
                 if st is not None:
                     losses.append(st["loss"])
+            _sync_buffers_from_rank0(sync, model)
             val = validate_dehazing(model, criterion, loader_for(val_loader, 0, val_steps, 500000), level, device)
             scheduler.step(val["val_loss"])
             if rank == 0:
                 print(f"Epoch {epoch + 1}/{epochs}:\n  Val Loss: {val['val_loss']:.4f}, Val PSNR: {val['val_psnr']:.2f}, "
                       f"Val SSIM: {val['val_ssim']:.4f}")
                 if val["val_psnr"] > best_val_psnr:
-                    torch.save(dehazing_checkpoint(model, optimizer, scheduler, epoch, val),
-                               os.path.join(ck_dir, "best_model.pth"))
+                    save_checkpoint_atomic(dehazing_checkpoint(model, optimizer, scheduler, epoch, val),
+                                           os.path.join(ck_dir, "best_model.pth"))
                     print(f"Saved best model with validation PSNR: {val['val_psnr']:.2f} dB")
                 if (epoch + 1) % 5 == 0:
-                    torch.save(dehazing_checkpoint(model, optimizer, scheduler, epoch, val),
-                               os.path.join(ck_dir, f"checkpoint_epoch_{epoch + 1}.pth"))
+                    save_checkpoint_atomic(dehazing_checkpoint(model, optimizer, scheduler, epoch, val),
+                                           os.path.join(ck_dir, f"checkpoint_epoch_{epoch + 1}.pth"))
             best_val_psnr = max(best_val_psnr, val["val_psnr"])
+            _barrier()   # train_all: the next stage's load_pretrained_model must not race rank 0's write
     finally:
         if sync is not None:
             sync.uninstall()
@@ -473,6 +532,11 @@ def evaluate_joint_model(config, test_loader=None, steps: int = 2, use_lpips: bo
     `<evaluation.results_dir>/joint_model_results.json` (schema of evaluation/metrics.py:117-124)."""
     from .metrics import CATEGORY_BY_LABEL, ImageQualityMetrics
     world, rank = _world_rank()
+    if world > 1 and rank != 0:
+        # every rank scoring its own shard and writing the same JSON concurrently was a race (ADVICE r2): rank 0 evaluates
+        # and writes, the others wait for it
+        _barrier()
+        return None
     system = build_joint_system(config, 1)
     dev = system["device"]
     ck = os.path.join(config["joint_training"]["checkpoint_dir"], "best_model.pth")
@@ -501,4 +565,6 @@ def evaluate_joint_model(config, test_loader=None, steps: int = 2, use_lpips: bo
     results = metrics.print_results()
     out_dir = config.get("evaluation", {}).get("results_dir", "results")
     metrics.save_results(os.path.join(out_dir, "joint_model_results.json"))
+    if world > 1:
+        _barrier()
     return results

@@ -387,8 +387,10 @@ int adh_bilinear_bwd(void* stream, const float* g, int g_cs, int N, int H, int W
 /* ---- training loop / evaluation harness around the hot path (csrc/train_io.hip) ------------------------------ */
 /* Multi-tensor Adam: ONE launch updates every listed tensor (training/train_joint.py:86-90,153-154;
  * training/train_dehazing.py:52-57,95-96 call torch.optim.Adam.step, one ATen op group per tensor).
- * table_dev[i] describes tensor i (device pointers; `step` = updates taken before this call; `repeats` = how many
- * times the reference lists the parameter, train_joint.py:81-84); chunks_dev holds nchunks pairs (tensor index, chunk
+ * table_dev[i] describes tensor i (device pointers; `step` = updates taken when the table was uploaded; `repeats` = how
+ * many times the reference lists the parameter, train_joint.py:81-84; the table may stay resident across calls:
+ * `calls_since_upload` calls have advanced every tensor by `repeats` each since then, so the host uploads it only when a
+ * pointer or the live set changes -- no per-step host-to-device copy); chunks_dev holds nchunks pairs (tensor index, chunk
  * index), a chunk being adh_adam_chunk_elems() consecutive floats.  g is read as g*grad_scale (1/world for summed
  * data-parallel gradients).  dup_mode 0: `repeats` consecutive full updates (torch's single-tensor loop: the CPU path
  * and every torch < 2.0); 1: torch >= 2.0's foreach form on CUDA (see train_io.hip).  max_repeats <= 4. */
@@ -404,7 +406,7 @@ typedef struct adh_adam_tensor {
 int adh_adam_chunk_elems(void);
 int adh_adam_multi(void* stream, const adh_adam_tensor* table_dev, const int32_t* chunks_dev, int nchunks, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, int dup_mode,
-                   int max_repeats);
+                   int max_repeats, int calls_since_upload);
 /* Synthetic fog on NCHW images, per-image beta / airlight: hazy = clip(clear*t + A*(1-t), 0, 1),
  * t = exp(-beta*(0.3 + 0.7*sqrt((x-0.5)^2 + (y-0.2)^2))) on the unit grid (utils/helpers.py:241-258, transmission in
  * float64 as numpy evaluates it). */

@@ -74,11 +74,23 @@ def main():
             dist.init_process_group(backend)
     seed_everything(config["seed"])
     from adam_dehaze_amd import train as T
+
+    def resume_for(stage):
+        """Bare `--resume`: every stage discovers the latest checkpoint in its own directory.  `--resume <file>`: the file
+        goes to the ONE stage that wrote it (a branch checkpoint loaded into another branch, or into the joint stage, used
+        to fail with a KeyError deep in the loader); the other stages of a multi-stage mode start fresh."""
+        if args.resume is None or args.resume is True:
+            return args.resume
+        owner = T.checkpoint_stage(args.resume, config)
+        if owner != stage:
+            print(f"--resume {args.resume}: a '{owner}' checkpoint; stage '{stage}' does not resume from it")
+            return None
+        return args.resume
     if args.mode == "train_joint":
-        T.train_joint_model(config, epochs=args.epochs, resume=args.resume)
+        T.train_joint_model(config, epochs=args.epochs, resume=resume_for("joint"))
     elif args.mode == "train_dehazing":
         for level in ("low", "medium", "high"):   # train_dehazing.py:216-232
-            T.train_dehazing_model(config, level, epochs=args.epochs or 30, resume=args.resume)
+            T.train_dehazing_model(config, level, epochs=args.epochs or 30, resume=resume_for(level))
     elif args.mode == "train_all":
         # main.py:121-139 of the reference: classifier -> dehazing branches -> joint -> evaluation.  Step 1 (stand-alone
         # classifier training) is outside this build's scope (DESIGN.md section 7): the joint step fine-tunes the classifier
@@ -86,9 +98,9 @@ def main():
         print("\n===== Step 1: fog-intensity classifier training is outside this build's scope: skipped =====")
         print("\n===== Step 2: Training Dehazing Models =====")
         for level in ("low", "medium", "high"):
-            T.train_dehazing_model(config, level, epochs=args.epochs or 30, resume=args.resume)
+            T.train_dehazing_model(config, level, epochs=args.epochs or 30, resume=resume_for(level))
         print("\n===== Step 3: Training Joint Model =====")
-        T.train_joint_model(config, epochs=args.epochs, resume=args.resume)
+        T.train_joint_model(config, epochs=args.epochs, resume=resume_for("joint"))
         print("\n===== Step 4: Evaluation (image quality; the detection half needs torchvision detection weights) =====")
         T.evaluate_joint_model(config)
     elif args.mode == "evaluate":

@@ -79,9 +79,12 @@ def test_joint_step_gradients_kink_matched():
     """T1 (train_joint.py:129-166) on the kink-matched gate: classifier (eval: its dropout is
     RNG-dependent in the reference's train mode) -> SoftRouter(T = 0.5) over the three train-mode branches -> the FULL
     JointLoss (L1 + 0.1 VGG16-content + 0.1 LPIPS + 0.2 CE) -> backward.  EVERY parameter of the three branches and of
-    the classifier head against the float64 oracle that replays the ReLU masks the branch kernels used (tests/_util.py):
-    err_gpu <= 5e-4 of the tensor's scale.  The loss networks' and the backbone's own ReLUs / max-pools run free in the
-    oracle (their masks are not replayable through max-pooling); the table goes to gpurun_out/grad_gate_joint.txt."""
+    the classifier head against the float64 oracle that replays the ReLU masks the branch kernels used (tests/_util.py).
+    Gate per tensor (the fixture gate of tests/test_gpu_parity.py): err_gpu <= 3 * err_ref + 3e-4 of the tensor's scale,
+    err_ref = the reference arithmetic itself (fp32 CPU oracle) with the SAME masks against that float64 run -- on this
+    composition the reference's own fp32 rounding is ~1e-3 on a few tensors, and kinks that cannot be replayed (CBAM
+    arg-max, max-pools of the loss networks, the backbone's ReLUs) are resolved by fp32 arithmetic on both sides.
+    The table goes to gpurun_out/grad_gate_joint.txt."""
     import os
     torch.manual_seed(1)
     with warnings.catch_warnings():
@@ -92,8 +95,7 @@ def test_joint_step_gradients_kink_matched():
     sds0 = {n: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for n, m in models.items()}
     vgg0 = {k: v.detach().cpu() for k, v in crit.dehazing_loss.content_loss.state_dict().items()}
     lp0 = {k: v.detach().cpu() for k, v in crit.dehazing_loss.perceptual_loss.state_dict().items()}
-    batch = next(T.synthetic_loader(4, 32, 1, seed=3, device=DEV))
-    hazy, clear, labels = batch["hazy"].cpu(), batch["clear"].cpu(), batch["intensity"].cpu()
+    hazy, clear, labels = R.synthetic_batch(4, 32, 32, seed=3)      # CPU-generated: the same batch on every box
     fns = {"low": R.lightweight_forward, "medium": R.medium_forward, "high": R.high_forward}
 
     def oracle(dtype, masks=None):
@@ -127,7 +129,7 @@ def test_joint_step_gradients_kink_matched():
     allm = km.masks()
     masks = {n: {k[len("models.%s." % n):]: v for k, v in allm.items() if k.startswith("models.%s." % n)} for n in fns}
     assert all(len(masks[n]) >= 5 for n in fns)
-    tot32, clf32, sds32 = oracle(torch.float32)
+    tot32, clf32, sds32 = oracle(torch.float32, masks)
     tot64, clf64, sds64 = oracle(torch.float64, masks)
     assert abs(float(total) - tot64) < 1e-4 * max(1.0, abs(tot64))
     bad, lines = [], []
@@ -136,8 +138,8 @@ def test_joint_step_gradients_kink_matched():
         scale = max(float(g64.abs().max()), 1e-6)
         err_gpu = float((g.cpu().double() - g64).abs().max()) / scale
         err_cpu = float((g32.double() - g64).abs().max()) / scale
-        lines.append(f"joint {tag:7s} {name:44s} scale {scale:.2e}  err_gpu {err_gpu:.2e}  (fp32 CPU oracle, free kinks: {err_cpu:.2e})")
-        if not err_gpu <= 5e-4:
+        lines.append(f"joint {tag:7s} {name:44s} scale {scale:.2e}  err_gpu {err_gpu:.2e}  err_ref {err_cpu:.2e}")
+        if not err_gpu <= 3 * err_cpu + 3e-4:
             bad.append((tag, name, err_gpu, err_cpu))
     for n, m in models.items():
         for name, p in m.named_parameters():

@@ -421,6 +421,28 @@ def test_resume_checkpoint_discovery(tmp_path):
     assert find_resume_checkpoint(d).endswith("checkpoint_epoch_10.pth")
 
 
+def test_explicit_resume_file_goes_to_the_stage_that_wrote_it(tmp_path):
+    """`--resume <file>` in a multi-stage mode handed one checkpoint to all three branches and the joint stage
+    (KeyError / cross-branch load).  train.checkpoint_stage names the owner by key set; mismatches raise ValueError."""
+    from adam_dehaze_amd import train as T
+    cfg = {"dehazing": {"low": {"model_type": "lightweight", "channels": 8, "blocks": 2},
+                        "medium": {"model_type": "standard", "channels": 8, "blocks": 6},
+                        "high": {"model_type": "complex", "channels": 16, "blocks": 9}}}
+    for level, factory in (("low", A.create_low_intensity_model), ("medium", A.create_medium_intensity_model),
+                           ("high", A.create_high_intensity_model)):
+        p = str(tmp_path / f"{level}.pth")
+        T.save_checkpoint_atomic({"epoch": 0, "model_state_dict": factory(cfg).state_dict()}, p)
+        assert T.checkpoint_stage(p, cfg) == level
+    pj = str(tmp_path / "joint.pth")
+    torch.save({"epoch": 1, "router_state_dict": {}}, pj)
+    assert T.checkpoint_stage(pj, cfg) == "joint"
+    with pytest.raises(ValueError, match="not a joint-training checkpoint"):
+        T.resume_joint({}, str(tmp_path / "low.pth"))
+    torch.save({"epoch": 1}, str(tmp_path / "junk.pth"))
+    with pytest.raises(ValueError):
+        T.checkpoint_stage(str(tmp_path / "junk.pth"), cfg)
+
+
 def test_loss_extractor_warnings_and_weight_loaders():
     """the VGG16 / LPIPS extractors start randomly initialised -- say so once; torchvision / lpips checkpoints
     load through key-remapping helpers (`features.{i}.*` -> `model.{i}.*`; `features.{i}.*` + `lin{k}.model.1.weight` ->

@@ -161,6 +161,70 @@ def _worker_agreements(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _worker_validation_and_checkpoints(rank, world, port, ret):
+    """(a) a rank whose validation shard holds no image of the branch's level (or whose loader is empty) must
+    still enter the all-reduce of the validation sums -- it used to return early and leave the others in the collective;
+    both ranks get the same sample-weighted result.  (b) buffers are taken from rank 0 before validation / checkpoints.
+    (c) checkpoints are written atomically and a barrier separates rank 0's write from the other ranks' reads."""
+    _init(rank, world, port)
+    import adam_dehaze_amd.train as T
+    from adam_dehaze_amd.parallel import GradientSynchronizer
+    # CPU stand-ins for the device metric kernels (the collective protocol is what is under test)
+    T.psnr_batch = lambda a, b: -10.0 * torch.log10(((a - b) ** 2).mean(dim=(1, 2, 3)))
+    T.ssim_batch = lambda a, b: torch.ones(a.shape[0])
+
+    class Model(torch.nn.Module):
+        def forward(self, x):
+            return x * 0.5
+
+    def crit(out, target):
+        l = (out - target).abs().mean()
+        return l, {"l1": l, "content": l * 0, "perceptual": l * 2, "total": l}
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.rand(4, 3, 8, 8, generator=g)
+    # rank 0: two images of level 1; rank 1: level 0 / 2 only -> nothing to validate there
+    labels = torch.tensor([1, 0, 1, 2]) if rank == 0 else torch.tensor([0, 2, 0, 2])
+    loader = [{"hazy": imgs, "clear": imgs * 0.9, "intensity": labels}]
+    val = T.validate_dehazing(Model(), crit, loader, 1, "cpu")
+    keep = torch.tensor([True, False, True, False])
+    want_loss = float((imgs[keep] * 0.5 - imgs[keep] * 0.9).abs().mean())
+    ok = val["val_samples"] == 2 and abs(val["val_loss"] - want_loss) < 1e-6 and abs(val["val_perceptual"] - 2 * want_loss) < 1e-6
+    # an entirely empty loader on one rank, joint flavour: every rank still reaches the collective and sees the same result
+    val2 = T.validate_dehazing(Model(), crit, loader if rank == 1 else [], 0, "cpu")
+    ok &= val2["val_samples"] == 2
+    both = [None, None]
+    dist.all_gather_object(both, (val, val2))
+    ok &= both[0] == both[1]
+    # (b) buffers from rank 0
+    torch.manual_seed(10 + rank)
+    m = torch.nn.BatchNorm2d(3)
+    m.running_mean.copy_(torch.randn(3))
+    w_before = m.weight.detach().clone() + rank
+    m.weight.data.copy_(w_before)
+    T._sync_buffers_from_rank0(GradientSynchronizer(list(m.parameters()), world), m)
+    got = [None, None]
+    dist.all_gather_object(got, (m.running_mean.tolist(), m.weight.tolist()))
+    ok &= got[0][0] == got[1][0] and got[0][1] != got[1][1]        # buffers agree; parameters are left alone
+    # (c) atomic save + barrier: rank 1 loads what rank 0 wrote, never a partial file, and no temp file is left behind
+    import tempfile
+    d = os.path.join(tempfile.gettempdir(), f"adh_ckpt_test_{port}")
+    path = os.path.join(d, "best_model.pth")
+    if rank == 0:
+        os.makedirs(d, exist_ok=True)
+        T.save_checkpoint_atomic({"epoch": 3, "model_state_dict": {"w": torch.randn(1 << 16)}}, path)
+    T._barrier()
+    ck = torch.load(path, map_location="cpu")
+    ok &= ck["epoch"] == 3 and ck["model_state_dict"]["w"].numel() == 1 << 16
+    ok &= [f for f in os.listdir(d) if ".tmp." in f] == []
+    T._barrier()
+    if rank == 0:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _spawn(fn, base):
     world = 2
     mgr = mp.Manager()
@@ -180,6 +244,10 @@ def test_overlapped_protocol_rebuild_and_unused_world2_gloo():
 
 def test_rank_agreements_world2_gloo():
     _spawn(_worker_agreements, 30700)
+
+
+def test_validation_collectives_buffers_and_atomic_checkpoints_world2_gloo():
+    _spawn(_worker_validation_and_checkpoints, 31300)
 
 
 def test_synchronizer_is_noop_for_single_rank():
