@@ -10,45 +10,46 @@
 // p^3] (dyadic constants, exact in fp32); the 1 / (N_a N_b) factors are applied in double by the reduce kernel.
 // 1/4 of the direct algorithm's MFMA work (the F(2x2,3x3)-domain kernel in conv_wgrad.hip: 4/9).
 //
-// Both MFMA operands are transformed data, so the transform cost per product is what decides the design.  A workgroup
-// owns 96 input channels x 96 output channels x ONE THIRD of the frequencies -- the row pairs {0,5}, {1,2}, {3,4} of the
-// 6x6 frequency grid, which are exactly the pairs the even/odd structure of the transforms produces together -- i.e.
-// 12 frequencies x 3 x 3 channel tiles = 108 accumulator tiles, 27 per wave (16 pinned to AGPRs).  Its first transform
-// pass then computes only its two rows (4 FMAs per column instead of 12) and every transformed value feeds three
-// MFMAs, which brings the VALU : MFMA ratio to that of the forward kernel.
-//   per strip of 6 tiles (4 rows x 24 pixels; K = 6 of the contraction):
-//     LDS-DMA   x halo [6][26 px][96 ci] and g [4][24 px][96 co], 2 pixels (48 lanes x 16 B) per instruction;
-//     pass 1    thread = (column, channel quad), loop over the 6 tiles: raw -> T[2 rows][6 | 4 columns]        (V planes)
-//     pass 2    thread = (row, channel quad, every second tile): T -> V[2][6] in place (x: B^T, g: [1,p,p^2,p^3])
-//     contract  wave w: frequencies 3w..3w+2 of the 12, per frequency and tile pair 3 + 3 ds_read_b32 feed 9 MFMAs
-//   raw is single buffered (152 KB of LDS in all): the next strip is staged as soon as pass 1 has consumed the current
-//   one and lands during pass 2 + contraction.  No global operand loads in the loop: all waits are compiler-visible.
-// Strips at the image border (and the ragged last strip of a row) zero the raw buffers and load with per-pixel lane masks.
+// Round 3 redesign.  The round-1 kernel gave a workgroup 96 x 96 channels x ONE THIRD of the frequencies: every tile
+// crossed L2 -> LDS three times (6.9 MAC per staged byte: 41 GB/s per CU at the MFMA rate, more than the path delivers),
+// its raw tiles were single buffered and its two-pass transform wrote every value to LDS twice at ~80 B/clk.  Now:
+//   * workgroup = 32 input channels x 96 output channels x ALL 36 frequencies: 11.7 MAC per staged byte (24 GB/s per CU);
+//     wave w owns frequencies 9w .. 9w+8 x 3 output-channel tiles = 27 accumulator tiles (16 pinned to AGPRs) -- the
+//     geometry of conv_wino43_kernel<3>'s contraction;
+//   * strips of 4 tiles (4 rows x 16 pixels of dL/dy, 6 x 18 halo of x; K = 4 tiles = two MFMA k-steps);
+//   * ONE transform pass, in registers: thread = (tile, channel quad, frequency row alpha): it applies the row transform
+//     for its alpha while it reads the raw columns (3-4 ds_read_b128 per column), then the column transform, and writes the
+//     six V values of its row: every transformed value is written to LDS once (ds_write_b128 runs at ~80 B/clk per CU
+//     -- the LDS write path, not the VALU, bounded the old two-pass form).  Lanes pair up rows that share their code:
+//     {1,2} and {3,4} differ in one constant's sign, {0,5} in the raw rows they read;
+//   * raw tiles arrive by LDS-DMA issued INSIDE the contraction (one piece behind the first MFMA of steps 0..10, as in
+//     conv_wino43_kernel): the raw buffers are free from the moment the transform has finished, the pieces land under
+//     the remaining contraction steps.  No global operand loads in the loop: all waits are compiler-visible;
+//   * conflict-free LDS images: x pixel slots of 128 B with a gap slot after every 4th pixel (tile pitch 5 slots = 160
+//     banks = 32 mod 64), dL/dy pixels of 384 B with the channel quads of odd tiles rotated by 8 (again 32 banks), so
+//     that the 16 lanes of a ds_read_b128 group -- two tiles x 8 quads -- hit 64 different banks.
+// Strips at the image border (and the ragged last strip of a row) zero the raw buffers and load with per-lane masks.
 // Output: slab[split][36][KP][NcP] partial sums; adh_wgrad_reduce_wino43 sums the splits and applies A'^T (.) A'.
-//
-// Status (round 1): parity-green, NOT the default (engine.USE_WINO43_WGRAD / ADH_WINO43_WGRAD=1 selects it): 3.9 / 3.7 / 3.7
-// ms on the 96 / 192 / 384-channel layers against 3.3 / 2.9 / 3.0 for the F(2x2,3x3)-domain kernel.  Compile-time
-// ablation (G4_DBG) at 96 channels: contraction 1.21 ms (= the MFMA floor for 174 GFLOP), pass 1 0.59, pass 2 0.66, and
-// 1.1 ms of the staging exposed although nothing waits on it before the next strip (staging alone runs at 8.5 TB/s of
-// L2 + HBM traffic: every input tile is read by the three frequency groups).  HBM traffic itself is as planned (4.25 GB
-// per launch, PMC: two of the three reads hit L2).  Spreading the DMA instructions over pass 2 and the contraction did
-// not help.  Next steps: fewer bytes per product (taller strips with a rolling halo; two frequency groups per
-// workgroup at 64 x 96 channels), balance the transform passes over all four waves.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
 
 #ifndef G4_DBG
-#define G4_DBG 0   // dev builds: 1 = skip pass 1, 2 = skip pass 2, 4 = skip the contraction, 8 = stage only the first strip
+#define G4_DBG 0   // dev builds: 1 = skip the transform, 4 = skip the contraction, 8 = stage only the first strip,
+                   // 16 = do not wait for the pieces (wrong results), 32 = pieces in one burst before the contraction
 #endif
-#define G4_T 6                                    // tiles per strip
-#define G4_XCOLS 26                               // halo columns of a strip
-#define G4_GCOLS 24
-#define G4_RAWX_F (6 * G4_XCOLS * 96)             // 14,976 floats
-#define G4_RAWG_F (4 * G4_GCOLS * 96)             //  9,216 floats
-#define G4_VPLANE (G4_T * 192)                    // floats per frequency plane: [tile][96 ci | 96 co]
-#define G4_V_F (12 * G4_VPLANE)                   // 13,824 floats
-#define G4_LDS_BYTES ((G4_RAWX_F + G4_RAWG_F + G4_V_F) * 4)
+#ifndef G4_STAGE_REGS
+#define G4_STAGE_REGS 0   // 1: raw tiles through registers (buffer_load_dwordx4 in steps 0..10, ds_write_b128 seven steps later) instead of LDS-DMA
+#endif
+#define G4_T 4                                    // tiles per strip
+#define G4_XROW 768                               // floats per raw x row: 24 slots x 32 channels (slot = col + col / 4)
+#define G4_RAWX_F (6 * G4_XROW)                   //  4,608 floats
+#define G4_GROW (16 * 96)                         // floats per raw dL/dy row
+#define G4_RAWG_F (4 * G4_GROW)                   //  6,144 floats
+#define G4_VPLANE (G4_T * 128)                    // floats per frequency plane: [tile][32 ci | 96 co]
+#define G4_V_F (36 * G4_VPLANE)                   // 18,432 floats
+#define G4_TAB_F (6 * 64)                         // per-lane global offsets of the six LDS-DMA piece patterns
+#define G4_LDS_BYTES ((G4_RAWX_F + G4_RAWG_F + G4_V_F + G4_TAB_F) * 4)     // 118,272 B
 
 #define G4_A 0.75f
 #define G4_B 1.25f
@@ -62,7 +63,7 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr5;
 struct Wg43Args {
     int TY, SX, S;         // tile rows, strips per tile row, total strips (N * TY * SX)
     int nsplit;
-    int ngroups, ncob;     // groups = cib x cob x 3 frequency groups
+    int ngroups, ncob;     // groups = (Cin / 32) x (Cout / 96)
     int KP;
 };
 
@@ -71,31 +72,26 @@ __device__ __forceinline__ void g4_mfma(f32x16& c, float a, float b) {
     if constexpr (IDX < 16) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-// local frequency FL (0..2 of this wave), nine MFMAs: 3 input-channel tiles x 3 output-channel tiles
-template <int FL, int MI, int NJ>
-__device__ __forceinline__ void g4_nine(f32x16 (&acc)[27], const float (&a)[3], const float (&b)[3]) {
-    if constexpr (MI < 3) {
-        g4_mfma<(FL * 3 + MI) * 3 + NJ>(acc[(FL * 3 + MI) * 3 + NJ], a[MI], b[NJ]);
-        if constexpr (NJ + 1 < 3) g4_nine<FL, MI, NJ + 1>(acc, a, b);
-        else g4_nine<FL, MI + 1, 0>(acc, a, b);
-    }
-}
-// step ST = FL * 3 + KS of 9: operands of step ST + 1 are read before the nine MFMAs of step ST are issued
+// step ST = fi * 2 + ks (local frequency fi of 9, tile pair ks of 2): operands of step ST + 1 are read before the three MFMAs
+// of step ST are issued; hook(ST) (one LDS-DMA piece of the next strip) sits behind the first MFMA
+// volatile: one ds_read_b32 per operand with a 16-bit immediate offset from ONE base register (hipcc otherwise pairs them
+// into ds_read2_b32, whose 8-bit offsets need a v_add_u32 on the base every step: VALU that comes out of the MFMA time)
+typedef const volatile __attribute__((address_space(3))) float* g4_lds_vf;
 template <int ST>
-__device__ __forceinline__ void g4_load_ops(const float* vlane, float (&a)[3], float (&b)[3]) {
-    const float* p = vlane + (ST / 3) * G4_VPLANE + (ST % 3) * 2 * 192;
+__device__ __forceinline__ void g4_load_ops(g4_lds_vf vlane, float& a, float (&b)[3]) {
+    g4_lds_vf p = vlane + (ST / 2) * G4_VPLANE + (ST % 2) * 256;
+    a = p[0];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) a[m] = p[m * 32];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) b[j] = p[96 + j * 32];
+    for (int j = 0; j < 3; ++j) b[j] = p[32 + j * 32];
 }
 template <int ST, typename Hook>
-__device__ __forceinline__ void g4_contract(f32x16 (&acc)[27], const float* vlane, float (&a)[2][3], float (&b)[2][3],
-                                            Hook&& hook) {
-    if constexpr (ST < 9) {
-        if constexpr (ST + 1 < 9) g4_load_ops<ST + 1>(vlane, a[(ST + 1) & 1], b[(ST + 1) & 1]);
-        hook(std::integral_constant<int, ST>{});      // (staging instructions of the next strip ride along)
-        g4_nine<ST / 3, 0, 0>(acc, a[ST & 1], b[ST & 1]);
+__device__ __forceinline__ void g4_contract(f32x16 (&acc)[27], g4_lds_vf vlane, float (&a)[2], float (&b)[2][3], Hook&& hook) {
+    if constexpr (ST < 18) {
+        if constexpr (ST + 1 < 18) g4_load_ops<ST + 1>(vlane, a[(ST + 1) & 1], b[(ST + 1) & 1]);
+        g4_mfma<(ST / 2) * 3 + 0>(acc[(ST / 2) * 3 + 0], a[ST & 1], b[ST & 1][0]);
+        hook(std::integral_constant<int, ST>{});
+        g4_mfma<(ST / 2) * 3 + 1>(acc[(ST / 2) * 3 + 1], a[ST & 1], b[ST & 1][1]);
+        g4_mfma<(ST / 2) * 3 + 2>(acc[(ST / 2) * 3 + 2], a[ST & 1], b[ST & 1][2]);
         g4_contract<ST + 1>(acc, vlane, a, b, hook);
     }
 }
@@ -107,17 +103,163 @@ __device__ __forceinline__ G4Neg g4_neg_constants() {
     return n;
 }
 
-// One launch for the three frequency groups fg = rows {0,5}, {1,2}, {3,4} of the 6x6 grid.  Block index -> (XCD, fg,
-// channel-block pair, split): the three groups of a split sit next to each other on one XCD and read the same strips at
-// the same time, so two of the three reads of every input tile hit that XCD's L2.  fg only selects constants and two
-// short code paths in the first transform pass (uniform branches).
+// ---------------------------------------------------------------------------------------------------- transform rounds
+// A round = 64 units (8 channel quads x 2 rows of a frequency-row pair x 4 tiles) of one operand: `begin` issues the loads
+// of raw column 0, `rows` applies the row transform column by column with the next column's loads in flight, `finish`
+// applies the column transform and writes the six V values.  The caller interleaves the rounds of a wave so that the
+// first loads of round i + 1 are in flight during finish(i) (one wave per SIMD: nothing else hides the LDS latency).
+template <int PAIR>
+struct G4X {
+    static constexpr int NL = PAIR == 0 ? 3 : 4;
+    f32x4 L[2][4];
+    f32x4 T[6];
+    const float* src;
+    float* dst;
+    float kp;
+    __device__ __forceinline__ void load(int c, f32x4 (&l)[4]) {
+        const float* s = src + (c + c / 4) * 32;
+        if constexpr (PAIR == 0) {
+            l[0] = *reinterpret_cast<const f32x4*>(s);
+            l[1] = *reinterpret_cast<const f32x4*>(s + 2 * G4_XROW);
+            l[2] = *reinterpret_cast<const f32x4*>(s + 4 * G4_XROW);
+        } else {
+            l[0] = *reinterpret_cast<const f32x4*>(s + G4_XROW);
+            l[1] = *reinterpret_cast<const f32x4*>(s + 2 * G4_XROW);
+            l[2] = *reinterpret_cast<const f32x4*>(s + 3 * G4_XROW);
+            l[3] = *reinterpret_cast<const f32x4*>(s + 4 * G4_XROW);
+        }
+    }
+    __device__ __forceinline__ void begin(const float* rawx, float* V, int t, int q8, int pb, const G4Neg ng) {
+        if constexpr (PAIR == 0) {
+            src = rawx + t * 160 + q8 * 4 + pb * G4_XROW;          // alpha 0: rows 0,2,4; alpha 5: rows 1,3,5
+            dst = V + pb * 5 * 6 * G4_VPLANE + t * 128 + q8 * 4;
+            kp = 0.f;
+        } else {
+            src = rawx + t * 160 + q8 * 4;
+            dst = V + (2 * PAIR - 1 + pb) * 6 * G4_VPLANE + t * 128 + q8 * 4;
+            kp = PAIR == 1 ? (pb ? ng.a : G4_A) : (pb ? ng.b : G4_B);
+        }
+        load(0, L[0]);
+    }
+    __device__ __forceinline__ void rows(const G4Neg ng) {
+        const float kxn = PAIR == 1 ? ng.b2 : ng.a2;                // rows 1,2: -b^2; rows 3,4: -a^2
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            if (c + 1 < 6) load(c + 1, L[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4(&l)[4] = L[c & 1];
+            if constexpr (PAIR == 0) T[c] = G4_A2B2 * l[0] + (ng.s2 * l[1] + l[2]);
+            else {
+                const f32x4 p = kxn * l[1] + l[3], qq = kxn * l[0] + l[2];
+                T[c] = kp * qq + p;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __device__ __forceinline__ void finish(const G4Neg ng) {
+        *reinterpret_cast<f32x4*>(dst) = G4_A2B2 * T[0] + (ng.s2 * T[2] + T[4]);
+        *reinterpret_cast<f32x4*>(dst + 5 * G4_VPLANE) = G4_A2B2 * T[1] + (ng.s2 * T[3] + T[5]);
+        {
+            const f32x4 p = ng.b2 * T[2] + T[4], qq = ng.b2 * T[1] + T[3];
+            *reinterpret_cast<f32x4*>(dst + 1 * G4_VPLANE) = G4_A * qq + p;
+            *reinterpret_cast<f32x4*>(dst + 2 * G4_VPLANE) = ng.a * qq + p;
+        }
+        {
+            const f32x4 r = ng.a2 * T[2] + T[4], s = ng.a2 * T[1] + T[3];
+            *reinterpret_cast<f32x4*>(dst + 3 * G4_VPLANE) = G4_B * s + r;
+            *reinterpret_cast<f32x4*>(dst + 4 * G4_VPLANE) = ng.b * s + r;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+// dL/dy rows of the pair PAIR for output-channel tile J: G' g G'^T with the un-normalised rows [1, p, p^2, p^3]
+template <int PAIR, int J>
+struct G4G {
+    f32x4 L[2][4];
+    f32x4 T[4];
+    const float* src;
+    float* dst;
+    float kp;
+    __device__ __forceinline__ void load(int c, f32x4 (&l)[4]) {
+        const float* s = src + c * 96;
+        l[0] = *reinterpret_cast<const f32x4*>(s);
+        if constexpr (PAIR != 0) {
+            l[1] = *reinterpret_cast<const f32x4*>(s + G4_GROW);
+            l[2] = *reinterpret_cast<const f32x4*>(s + 2 * G4_GROW);
+            l[3] = *reinterpret_cast<const f32x4*>(s + 3 * G4_GROW);
+        }
+    }
+    __device__ __forceinline__ void begin(const float* rawg, float* V, int t, int q8, int pb, const G4Neg ng) {
+        // the channel quads of odd tiles sit rotated by 8 in the raw image (bank spreading): tile J lives at (J + (t & 1)) % 3
+        const int jq = ((t & 1) ? ((J + 1) % 3) : J) * 32 + q8 * 4;
+        if constexpr (PAIR == 0) {
+            src = rawg + t * 384 + jq + pb * 3 * G4_GROW;           // alpha 0: row 0; alpha 5: row 3
+            dst = V + pb * 5 * 6 * G4_VPLANE + t * 128 + 32 + J * 32 + q8 * 4;
+            kp = 0.f;
+        } else {
+            src = rawg + t * 384 + jq;
+            dst = V + (2 * PAIR - 1 + pb) * 6 * G4_VPLANE + t * 128 + 32 + J * 32 + q8 * 4;
+            kp = PAIR == 1 ? (pb ? ng.a : G4_A) : (pb ? ng.b : G4_B);
+        }
+        load(0, L[0]);
+    }
+    __device__ __forceinline__ void rows(const G4Neg ng) {
+        const float kg2 = PAIR == 1 ? G4_A2 : G4_B2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c + 1 < 4) load(c + 1, L[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4(&l)[4] = L[c & 1];
+            if constexpr (PAIR == 0) T[c] = l[0];
+            else {
+                const f32x4 e = kg2 * l[2] + l[0], o = kg2 * l[3] + l[1];
+                T[c] = kp * o + e;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __device__ __forceinline__ void finish(const G4Neg ng) {
+        *reinterpret_cast<f32x4*>(dst) = T[0];
+        *reinterpret_cast<f32x4*>(dst + 5 * G4_VPLANE) = T[3];
+        {
+            const f32x4 ea = G4_A2 * T[2] + T[0], oa = G4_A2 * T[3] + T[1];
+            *reinterpret_cast<f32x4*>(dst + 1 * G4_VPLANE) = G4_A * oa + ea;
+            *reinterpret_cast<f32x4*>(dst + 2 * G4_VPLANE) = ng.a * oa + ea;
+        }
+        {
+            const f32x4 eb = G4_B2 * T[2] + T[0], ob = G4_B2 * T[3] + T[1];
+            *reinterpret_cast<f32x4*>(dst + 3 * G4_VPLANE) = G4_B * ob + eb;
+            *reinterpret_cast<f32x4*>(dst + 4 * G4_VPLANE) = ng.b * ob + eb;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+// three rounds of one wave, software pipelined: begin(i + 1) before finish(i)
+template <typename R0, typename R1, typename R2>
+__device__ __forceinline__ void g4_three_rounds(const float* raw0, const float* raw1, const float* raw2, float* V, int t, int q8,
+                                                int pb, const G4Neg ng) {
+    R0 r0;
+    r0.begin(raw0, V, t, q8, pb, ng);
+    r0.rows(ng);
+    R1 r1;
+    r1.begin(raw1, V, t, q8, pb, ng);
+    r0.finish(ng);
+    r1.rows(ng);
+    R2 r2;
+    r2.begin(raw2, V, t, q8, pb, ng);
+    r1.finish(ng);
+    r2.rows(ng);
+    r2.finish(ng);
+}
+
+// Block index -> (XCD, channel-block pair, split): the workgroups of a split sit next to each other on one XCD and walk
+// the same strips at the same time, so the dL/dy tile that the Cin / 32 input-channel groups share (and the x slices
+// the Cout / 96 output groups share) are served by that XCD's L2 after the first read.
 __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_conv_desc d, const Wg43Args g,
                                                                    float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // rawx | rawg | V
     const int bid = blockIdx.x;
-    const int qd = bid >> 3;
-    const int fg = qd % 3;
-    const int q2 = qd / 3;
+    const int q2 = bid >> 3;
     const int grp = q2 % g.ngroups;
     const int split = (q2 / g.ngroups) * 8 + (bid & 7);
     if (split >= g.nsplit) return;
@@ -132,39 +274,115 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
     const int cob = grp % g.ncob, cib = grp / g.ncob;
 
     const int xcs = d.in_cstride * 4, gcs = d.out_cstride * 4;       // pixel pitches in bytes
-    // per-lane DMA offsets: 2 pixels x 24 channel quads per instruction (lanes 48..63 idle)
-    const int pj = lane >= 24 ? 1 : 0, pq = lane - 24 * pj;
-    const int vox = pj * xcs + pq * 16 + cib * 384, vog = pj * gcs + pq * 16 + cob * 384;
-    const bool dma_lane = lane < 48;
+    // per-lane global offsets of the LDS-DMA pieces (a piece = 1 KB of the LDS image = 64 lanes x 16 B):
+    //   x row = 3 pieces: lane -> slot u = 8 k + lane / 8 -> halo column u - u / 5 (gap and spare slots load a duplicate)
+    //   dL/dy row = 6 pieces, pieces k and k + 3 are 8 pixels apart: lane -> (pixel, rotated channel quad)
+    auto x_pattern = [&](const int k) {
+        const int u = 8 * k + (lane >> 3);
+        return adh_min_i(u - u / 5, 17) * xcs + (lane & 7) * 16 + cib * 128;
+    };
+    auto g_pattern = [&](const int k) {
+        const int b = 1024 * k + 16 * lane;
+        const int px = b / 384, qpos = (b % 384) / 16;
+        return px * gcs + ((qpos + 24 - 8 * ((px >> 2) & 1)) % 24) * 16 + cob * 384;
+    };
+    // (kept in LDS, one ds_read_b32 per piece: six more live VGPRs across the transform phase made hipcc spill them and
+    // reload them from scratch inside the contraction, where every scratch wait also drains the LDS-DMA pieces in flight)
+    int* const tab = reinterpret_cast<int*>(lds + G4_RAWX_F + G4_RAWG_F + G4_V_F);
+    if (tid < 64) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            tab[k * 64 + tid] = x_pattern(k);
+            tab[(3 + k) * 64 + tid] = g_pattern(k);
+        }
+    }
+    __syncthreads();
 
     const G4Neg ng = g4_neg_constants();
-    // first-pass constants of this frequency group (fg = 1: points +-a, fg = 2: points +-b)
-    const float kp = fg == 1 ? G4_A : G4_B, kn = fg == 1 ? ng.a : ng.b;
-    const float kxn = fg == 1 ? ng.b2 : ng.a2, kg2 = fg == 1 ? G4_A2 : G4_B2;
 
-    // stage strip s (uniform): raw buffers <- x halo and g tile.  Descriptors cover the whole tensors (x shifted by one row
-    // + one pixel so that every scalar offset is non-negative); pixel pairs: wave w takes pairs w, w + 4, w + 8 (+ 12)
-    // of every row -- 24 / 18 / 18 / 18 x pairs + 12 g pairs per wave, one LDS-DMA instruction each
+    // Descriptors cover the whole tensors (x shifted by one row + one pixel so that every scalar offset is non-negative)
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(d.in) - (int64_t)(d.IW + 1) * xcs), 0, 0xffffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.out), 0, 0xffffffff, 0x00020000);
     const unsigned xrow = (unsigned)d.IW * xcs, grow = (unsigned)d.VW * gcs;
-    float* const rawx_w = rawx + wave * 2 * 96;
-    float* const rawg_w = rawg + wave * 2 * 96;
-    // one staging instruction of an interior strip: slot i < 24 = x pair (row i / 4, k = i % 4), else g pair
-    auto dma_slot = [&](const int i, const unsigned xb, const unsigned gb) {
-        if (i < 24) {
-            const int row = i >> 2, k = i & 3;
-            if (k < 3 || wave == 0)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr5)(rawx_w + (row * G4_XCOLS + 8 * k) * 96), 16, vox,
-                                                         xb + row * xrow + k * 8 * xcs, 0, 0);
-        } else {
-            const int row = (i - 24) / 3, k = (i - 24) % 3;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void_ptr5)(rawg_w + (row * G4_GCOLS + 8 * k) * 96), 16, vog,
-                                                     gb + row * grow + k * 8 * gcs, 0, 0);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_ptr5)lds;     // 32-bit LDS address of the dynamic segment
+    // LDS destination (M0) and scalar offset go through readfirstlane at the point of use: hipcc otherwise carries some
+    // of these wave-uniform values in VGPRs across the loop and issues the piece from a waterfall loop
+    auto dma_x = [&](const int row, auto kc, const unsigned xb, const int pat) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(row * G4_XROW + k * 256) * 4);
+        const unsigned so = __builtin_amdgcn_readfirstlane(xb + row * xrow);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr5)(uintptr_t)ldsa, 16, pat, so, 0, 0);
+    };
+    auto dma_g = [&](const int row, auto kc, const unsigned gb, const int pat) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(G4_RAWX_F + row * G4_GROW + k * 256) * 4);
+        const unsigned so = __builtin_amdgcn_readfirstlane(gb + row * grow + (k / 3) * 8 * gcs);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void_ptr5)(uintptr_t)ldsa, 16, pat, so, 0, 0);
+    };
+    // piece schedule of an interior strip: wave w stages dL/dy row w (steps 0..5), x row w (6..8) and its share of x rows
+    // 4 and 5 (9, 10): 11 / 11 / 10 / 10 pieces per wave
+    // the six per-lane patterns, read from the table at the start of every staging sequence (volatile: a hoisted read
+    // would be six more VGPRs live across the transform phase)
+    struct Pat { int x0, x1, x2, g0, g1, g2; };
+    auto load_patterns = [&]() {
+        typedef const volatile __attribute__((address_space(3))) int* lds_vi;
+        lds_vi t = (lds_vi)(tab + lane);
+        Pat p;
+        p.g0 = t[3 * 64]; p.g1 = t[4 * 64]; p.g2 = t[5 * 64];
+        p.x0 = t[0]; p.x1 = t[64]; p.x2 = t[128];
+        return p;
+    };
+    auto stage_piece = [&](auto stc, const unsigned xb, const unsigned gb, const Pat& p) {
+        constexpr int ST = decltype(stc)::value;
+        if constexpr (ST < 6) dma_g(wave, std::integral_constant<int, ST>{}, gb, ST % 3 == 0 ? p.g0 : (ST % 3 == 1 ? p.g1 : p.g2));
+        else if constexpr (ST < 9) dma_x(wave, std::integral_constant<int, ST - 6>{}, xb, ST == 6 ? p.x0 : (ST == 7 ? p.x1 : p.x2));
+        else if constexpr (ST == 9) {
+            if (wave == 0) dma_x(4, std::integral_constant<int, 0>{}, xb, p.x0);
+            else if (wave == 1) dma_x(4, std::integral_constant<int, 2>{}, xb, p.x2);
+            else if (wave == 2) dma_x(5, std::integral_constant<int, 1>{}, xb, p.x1);
+            else dma_x(5, std::integral_constant<int, 2>{}, xb, p.x2);
+        } else if constexpr (ST == 10) {
+            if (wave == 0) dma_x(4, std::integral_constant<int, 1>{}, xb, p.x1);
+            else if (wave == 1) dma_x(5, std::integral_constant<int, 0>{}, xb, p.x0);
         }
     };
-    // strip s -> scalar offsets of this wave's first pair; returns whether the strip is interior
+    auto stage_interior = [&](const unsigned xb, const unsigned gb) {
+        const Pat p = load_patterns();
+        stage_piece(std::integral_constant<int, 0>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 1>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 2>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 3>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 4>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 5>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 6>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 7>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 8>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 9>{}, xb, gb, p);
+        stage_piece(std::integral_constant<int, 10>{}, xb, gb, p);
+    };
+    // register-staged form of the same pieces: (LDS byte address, scalar offset, pattern, resource) of piece ST of this wave
+    auto piece_of = [&](auto stc, const unsigned xb, const unsigned gb, const Pat& p, unsigned& ldsa, unsigned& so, int& pat, bool& isg) {
+        constexpr int ST = decltype(stc)::value;
+        if constexpr (ST < 6) {
+            isg = true;
+            ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(G4_RAWX_F + wave * G4_GROW + ST * 256) * 4);
+            so = __builtin_amdgcn_readfirstlane(gb + wave * grow + (ST / 3) * 8 * gcs);
+            pat = ST % 3 == 0 ? p.g0 : (ST % 3 == 1 ? p.g1 : p.g2);
+            return true;
+        } else {
+            isg = false;
+            int row = wave, k = ST - 6;
+            bool valid = true;
+            if constexpr (ST == 9) { row = wave < 2 ? 4 : 5; k = wave == 0 ? 0 : (wave == 2 ? 1 : 2); }
+            if constexpr (ST == 10) { row = 4 + wave; k = 1 - wave; valid = wave < 2; }
+            ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(row * G4_XROW + k * 256) * 4);
+            so = __builtin_amdgcn_readfirstlane(xb + row * xrow);
+            pat = k == 0 ? p.x0 : (k == 1 ? p.x1 : p.x2);
+            return valid;
+        }
+    };
+    // strip s -> scalar offsets of its first halo pixel / first dL/dy pixel; returns whether the strip is interior
     auto strip_origin = [&](int s, int& y0, int& x0, unsigned& xb, unsigned& gb) {
         int r = s;
         const int sx = r % g.SX;
@@ -172,136 +390,59 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
         const int ty = r % g.TY;
         const int n = r / g.TY;
         y0 = ty * 4;
-        x0 = sx * 24;
-        xb = __builtin_amdgcn_readfirstlane((unsigned)((n * d.IH + y0) * d.IW + x0 + 2 * wave) * xcs);
-        gb = __builtin_amdgcn_readfirstlane((unsigned)((n * d.VH + y0) * d.VW + x0 + 2 * wave) * gcs);
-        return y0 >= 1 && y0 + 5 <= d.IH && x0 >= 1 && x0 + 25 <= d.IW;
+        x0 = sx * 16;
+        xb = __builtin_amdgcn_readfirstlane((unsigned)((n * d.IH + y0) * d.IW + x0) * xcs);
+        gb = __builtin_amdgcn_readfirstlane((unsigned)((n * d.VH + y0) * d.VW + x0) * gcs);
+        return y0 >= 1 && y0 + 5 <= d.IH && x0 >= 1 && x0 + 17 <= d.IW;
     };
-    // all 36 slots at once (first strip of a split)
-    auto stage_interior = [&](unsigned xb, unsigned gb) {
-        if (dma_lane) {
-#pragma unroll
-            for (int i = 0; i < 36; ++i) dma_slot(i, xb, gb);
-        }
-    };
-    // border strip: zero both raw buffers, then load only the pixels inside the image
-    auto stage_border = [&](int y0, int x0, unsigned xb, unsigned gb) {
+    // border strip: zero both raw buffers, then load only the pixels inside the image (x rows w, w + 4; dL/dy row w)
+    auto stage_border = [&](const int sb) {
+        int y0, x0;
+        unsigned xb, gb;
+        (void)strip_origin(sb, y0, x0, xb, gb);   // recomputed here: nothing of it stays live across the contraction
+        int ln = lane, td = tid;                  // opaque copies: keeps LICM from hoisting this rare path's lane predicates
+        asm volatile("" : "+v"(ln), "+v"(td));   // (nine 64-bit masks + their operands) out of the strip loop
+        const Pat bp = load_patterns();
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < (G4_RAWX_F + G4_RAWG_F) / 4; i += 256) *reinterpret_cast<f32x4*>(lds + i * 4) = z;
+        for (int i = td; i < (G4_RAWX_F + G4_RAWG_F) / 4; i += 256) *reinterpret_cast<f32x4*>(lds + i * 4) = z;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll 1
-        for (int row = 0; row < 6; ++row) {
+        for (int row = wave; row < 6; row += 4) {
             const int iy = y0 - 1 + row;
-#pragma unroll 1
-            for (int k = 0; k < 4; ++k) {
-                const int ix = x0 - 1 + 2 * (wave + 4 * k) + pj;
-                if ((k < 3 || wave == 0) && dma_lane && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr5)(rawx_w + (row * G4_XCOLS + 8 * k) * 96), 16, vox,
-                                                             xb + row * xrow + k * 8 * xcs, 0, 0);
-            }
+            const bool rowok = iy >= 0 && iy < d.IH;
+            auto one = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int u = 8 * k + (ln >> 3);
+                const int ix = x0 - 1 + u - u / 5;
+                if (rowok && (u % 5) != 4 && u < 22 && ix >= 0 && ix < d.IW) dma_x(row, kc, xb, k == 0 ? bp.x0 : (k == 1 ? bp.x1 : bp.x2));
+            };
+            one(std::integral_constant<int, 0>{});
+            one(std::integral_constant<int, 1>{});
+            one(std::integral_constant<int, 2>{});
         }
-#pragma unroll 1
-        for (int row = 0; row < 4; ++row)
-#pragma unroll 1
-            for (int k = 0; k < 3; ++k) {
-                const int gx = x0 + 2 * (wave + 4 * k) + pj;
-                if (dma_lane && gx < d.VW)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void_ptr5)(rawg_w + (row * G4_GCOLS + 8 * k) * 96), 16, vog,
-                                                             gb + row * grow + k * 8 * gcs, 0, 0);
-            }
+        {
+            auto one = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int px = (1024 * (k % 3) + 16 * ln) / 384 + 8 * (k / 3);
+                if (x0 + px < d.VW) dma_g(wave, kc, gb, k % 3 == 0 ? bp.g0 : (k % 3 == 1 ? bp.g1 : bp.g2));
+            };
+            one(std::integral_constant<int, 0>{});
+            one(std::integral_constant<int, 1>{});
+            one(std::integral_constant<int, 2>{});
+            one(std::integral_constant<int, 3>{});
+            one(std::integral_constant<int, 4>{});
+            one(std::integral_constant<int, 5>{});
+        }
     };
 
-    // ------------------------------------------------------------------ transforms
-    const int slot = (tid * 171) >> 12;             // tid / 24 for tid < 256
-    const int q4 = (tid - slot * 24) * 4;           // channel quad offset (floats)
-    // pass 1: slot 0..5 = x column, 6..9 = g column, 10 = idle; loop over the six tiles
-    auto pass1 = [&]() {
-        if (slot < 6) {
-            const float* src = rawx + slot * 96 + q4;
-            float* dst = V + slot * G4_VPLANE + q4;
-#pragma unroll
-            for (int t = 0; t < G4_T; ++t) {
-                const float* s = src + t * 4 * 96;
-                f32x4 o0, o1;
-                if (fg == 0) {
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(s), d1 = *reinterpret_cast<const f32x4*>(s + G4_XCOLS * 96),
-                                d2 = *reinterpret_cast<const f32x4*>(s + 2 * G4_XCOLS * 96),
-                                d3 = *reinterpret_cast<const f32x4*>(s + 3 * G4_XCOLS * 96),
-                                d4 = *reinterpret_cast<const f32x4*>(s + 4 * G4_XCOLS * 96),
-                                d5 = *reinterpret_cast<const f32x4*>(s + 5 * G4_XCOLS * 96);
-                    o0 = G4_A2B2 * d0 + (ng.s2 * d2 + d4);
-                    o1 = G4_A2B2 * d1 + (ng.s2 * d3 + d5);
-                } else {
-                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(s + G4_XCOLS * 96),
-                                d2 = *reinterpret_cast<const f32x4*>(s + 2 * G4_XCOLS * 96),
-                                d3 = *reinterpret_cast<const f32x4*>(s + 3 * G4_XCOLS * 96),
-                                d4 = *reinterpret_cast<const f32x4*>(s + 4 * G4_XCOLS * 96);
-                    const f32x4 p = kxn * d2 + d4, qq = kxn * d1 + d3;      // kxn = -b^2 (rows 1,2) / -a^2 (rows 3,4)
-                    o0 = kp * qq + p;                                        // kp = a / b, kn = -kp
-                    o1 = kn * qq + p;
-                }
-                *reinterpret_cast<f32x4*>(dst + t * 192) = o0;
-                *reinterpret_cast<f32x4*>(dst + 6 * G4_VPLANE + t * 192) = o1;
-                __builtin_amdgcn_sched_barrier(0);   // one tile of loads in flight, not six (registers)
-            }
-        } else if (slot < 10) {
-            const float* src = rawg + (slot - 6) * 96 + q4;
-            float* dst = V + (slot - 6) * G4_VPLANE + 96 + q4;
-#pragma unroll
-            for (int t = 0; t < G4_T; ++t) {
-                const float* s = src + t * 4 * 96;
-                f32x4 o0, o1;
-                if (fg == 0) {
-                    o0 = *reinterpret_cast<const f32x4*>(s);
-                    o1 = *reinterpret_cast<const f32x4*>(s + 3 * G4_GCOLS * 96);
-                } else {
-                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(s), g1 = *reinterpret_cast<const f32x4*>(s + G4_GCOLS * 96),
-                                g2 = *reinterpret_cast<const f32x4*>(s + 2 * G4_GCOLS * 96),
-                                g3 = *reinterpret_cast<const f32x4*>(s + 3 * G4_GCOLS * 96);
-                    const f32x4 e = kg2 * g2 + g0, o = kg2 * g3 + g1;        // kg2 = a^2 / b^2
-                    o0 = kp * o + e;
-                    o1 = kn * o + e;
-                }
-                *reinterpret_cast<f32x4*>(dst + t * 192) = o0;
-                *reinterpret_cast<f32x4*>(dst + 6 * G4_VPLANE + t * 192) = o1;
-                __builtin_amdgcn_sched_barrier(0);   // one tile of loads in flight, not six (registers)
-            }
-        }
-    };
-    // pass 2: slot 0..7: role = slot & 3 (x row 0, x row 1, g row 0, g row 1), tiles (slot >> 2) + {0, 2, 4}
-    auto pass2 = [&](const int k) {
-        if (slot < 8) {
-            const int role = slot & 3;
-            float* pv = V + (role & 1) * 6 * G4_VPLANE + (role >> 1) * 96 + q4 + ((slot >> 2) + 2 * k) * 192;
-            if (role < 2) {
-                f32x4 t[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) t[c] = *reinterpret_cast<const f32x4*>(pv + c * G4_VPLANE);
-                const f32x4 v0 = G4_A2B2 * t[0] + (ng.s2 * t[2] + t[4]);
-                const f32x4 v5 = G4_A2B2 * t[1] + (ng.s2 * t[3] + t[5]);
-                const f32x4 p = ng.b2 * t[2] + t[4], r = ng.a2 * t[2] + t[4];
-                const f32x4 qq = ng.b2 * t[1] + t[3], s = ng.a2 * t[1] + t[3];
-                *reinterpret_cast<f32x4*>(pv) = v0;
-                *reinterpret_cast<f32x4*>(pv + 1 * G4_VPLANE) = G4_A * qq + p;
-                *reinterpret_cast<f32x4*>(pv + 2 * G4_VPLANE) = ng.a * qq + p;
-                *reinterpret_cast<f32x4*>(pv + 3 * G4_VPLANE) = G4_B * s + r;
-                *reinterpret_cast<f32x4*>(pv + 4 * G4_VPLANE) = ng.b * s + r;
-                *reinterpret_cast<f32x4*>(pv + 5 * G4_VPLANE) = v5;
-            } else {
-                f32x4 t[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) t[c] = *reinterpret_cast<const f32x4*>(pv + c * G4_VPLANE);
-                const f32x4 ea = G4_A2 * t[2] + t[0], oa = G4_A2 * t[3] + t[1];
-                const f32x4 eb = G4_B2 * t[2] + t[0], ob = G4_B2 * t[3] + t[1];
-                *reinterpret_cast<f32x4*>(pv + 1 * G4_VPLANE) = G4_A * oa + ea;     // (plane 0 already holds t[0])
-                *reinterpret_cast<f32x4*>(pv + 2 * G4_VPLANE) = ng.a * oa + ea;
-                *reinterpret_cast<f32x4*>(pv + 3 * G4_VPLANE) = G4_B * ob + eb;
-                *reinterpret_cast<f32x4*>(pv + 4 * G4_VPLANE) = ng.b * ob + eb;
-                *reinterpret_cast<f32x4*>(pv + 5 * G4_VPLANE) = t[3];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    // ------------------------------------------------------------------ transform roles (58 / 58 / 52 / 60 float4 FMAs)
+    const int q8 = lane & 7, pb = (lane >> 3) & 1, tt = lane >> 4;
+    auto transform = [&]() {
+        if (wave == 0) g4_three_rounds<G4X<1>, G4G<1, 0>, G4G<0, 0>>(rawx, rawg, rawg, V, tt, q8, pb, ng);
+        else if (wave == 1) g4_three_rounds<G4X<2>, G4G<2, 0>, G4G<0, 1>>(rawx, rawg, rawg, V, tt, q8, pb, ng);
+        else if (wave == 2) g4_three_rounds<G4X<0>, G4G<1, 1>, G4G<0, 2>>(rawx, rawg, rawg, V, tt, q8, pb, ng);
+        else g4_three_rounds<G4G<1, 2>, G4G<2, 1>, G4G<2, 2>>(rawg, rawg, rawg, V, tt, q8, pb, ng);
     };
 
     // ------------------------------------------------------------------ main loop over this split's strips
@@ -310,10 +451,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
     for (int t = 0; t < 27; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // A / B operand lane address: V[3 * wave + fl][2 * ks + h][mi * 32 + l31 | 96 + nj * 32 + l31]
-    const float* const vlane = V + (3 * wave) * G4_VPLANE + h * 192 + l31;
+    // A / B operand lane address: V[9 * wave + fi][2 * ks + h][l31 | 32 + nj * 32 + l31]
+    g4_lds_vf const vlane = (g4_lds_vf)(V + (9 * wave) * G4_VPLANE + h * 128 + l31);
 
-    // this split's strips: a contiguous range (the three frequency-group workgroups of a split walk it together)
+    // this split's strips: a contiguous range (the workgroups of a split walk it together)
     const int per = (g.S + g.nsplit - 1) / g.nsplit;
     int s = split * per;
     const int s_end = adh_min_i(s + per, g.S);
@@ -321,55 +462,87 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
         int y0, x0;
         unsigned xb, gb;
         if (strip_origin(s, y0, x0, xb, gb)) stage_interior(xb, gb);
-        else stage_border(y0, x0, xb, gb);
+        else stage_border(s);
     }
 #pragma unroll 1
     while (s < s_end) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();            // strip s landed; every wave is past the previous contraction
-        if (!(G4_DBG & 1)) pass1();
+        if (!(G4_DBG & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // strip s landed; every wave is past the previous contraction (V is free)
+        if (!(G4_DBG & 1)) transform();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();            // raw consumed, T complete
-        // stage the next strip: it lands during pass 2 + contraction.  (Spreading the 36 instructions of a wave over the
-        // pass-2 steps and the first contraction steps instead of issuing them back to back was measured: 4 % slower.)
+        __builtin_amdgcn_s_barrier();            // V complete, raw consumed: the next strip may land
         const int sn = s + 1;
-        if (sn < s_end && !(G4_DBG & 8)) {
-            int y0, x0;
-            unsigned xb, gb;
-            if (strip_origin(sn, y0, x0, xb, gb)) stage_interior(xb, gb);
-            else stage_border(y0, x0, xb, gb);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (!(G4_DBG & 2)) pass2(k);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        int y0 = 0, x0 = 0;
+        unsigned xb = 0, gb = 0;
+        const bool more = sn < s_end && !(G4_DBG & 8);
+        const bool inner = more && strip_origin(sn, y0, x0, xb, gb);
+        if (G4_DBG & 64) { xb = (unsigned)(d.IW + 1) * xcs; gb = 0; }   // dev: every strip stages the same (L2-resident) pixels
         if (!(G4_DBG & 4)) {
-            float oa[2][3], ob[2][3];
+            float oa[2], ob[2][3];
             g4_load_ops<0>(vlane, oa[0], ob[0]);
-            g4_contract<0>(acc, vlane, oa, ob, [](auto) {});
+            if ((G4_DBG & 32) && inner) stage_interior(xb, gb);
+            const Pat pt = load_patterns();
+            if constexpr (G4_STAGE_REGS) {
+                constexpr int LAG = 5;                       // steps between a load and its LDS write (5 x 192 MFMA cycles)
+                f32x4 stg[11];
+                // LDS write addresses: three per-lane bases defined HERE (opaque: hoisted out of the strip loop they would be live
+                // across the transform phase) + immediates
+                unsigned bx = lane * 16 + wave * (G4_XROW * 4), bg = lane * 16 + (G4_RAWX_F + wave * G4_GROW) * 4, b0 = lane * 16;
+                asm volatile("" : "+v"(bx), "+v"(bg), "+v"(b0));
+                // a strip without an interior successor still issues the loads (from the tensors' first pixels) and skips the writes:
+                // one instruction stream, no accumulator phis
+                const unsigned xb1 = inner ? xb : (unsigned)(d.IW + 1) * xcs, gb1 = inner ? gb : 0u;
+                g4_contract<0>(acc, vlane, oa, ob, [&](auto stc) {
+                    constexpr int ST = decltype(stc)::value;
+                    if constexpr (ST < 11) {
+                        unsigned ldsa, so;
+                        int pat;
+                        bool isg;
+                        (void)piece_of(stc, xb1, gb1, pt, ldsa, so, pat, isg);
+                        stg[ST] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(isg ? gr : xr, pat, so, 0));
+                    }
+                    if constexpr (ST >= LAG && ST - LAG < 11) {
+                        constexpr int P = ST - LAG;
+                        unsigned ldsa = 0, so;
+                        int pat;
+                        bool isg;
+                        typedef __attribute__((address_space(3))) f32x4* lds_f4;
+                        if constexpr (P < 6) {
+                            if (inner) *(lds_f4)(uintptr_t)(bg + P * 1024) = stg[P];
+                        } else if constexpr (P < 9) {
+                            if (inner) *(lds_f4)(uintptr_t)(bx + (P - 6) * 1024) = stg[P];
+                        } else {
+                            const bool valid = piece_of(std::integral_constant<int, P>{}, xb1, gb1, pt, ldsa, so, pat, isg) && inner;
+                            if (valid) *(lds_f4)(uintptr_t)(b0 + (ldsa - lds0)) = stg[P];
+                        }
+                    }
+                });
+            } else {
+                g4_contract<0>(acc, vlane, oa, ob, [&](auto stc) {
+                    if constexpr (decltype(stc)::value < 11 && !(G4_DBG & 32)) {
+                        if (inner) stage_piece(stc, xb, gb, pt);
+                    }
+                });
+            }
+        } else if (inner) {
+            stage_interior(xb, gb);
         }
+        if (more && !inner) stage_border(sn);
         s = sn;
     }
 
     // ------------------------------------------------------------------ partial sums -> slab[split][f][KP][NcP]
-    // local frequency fl = a' * 6 + b  ->  global row {0,5} / {1,2} / {3,4}[a']
     float* const sl = slab + (int64_t)split * 36 * g.KP * d.NcP;
 #pragma unroll
-    for (int fi = 0; fi < 3; ++fi) {
-        const int fl = 3 * wave + fi;
-        const int ap = fl >= 6 ? 1 : 0, b = fl - 6 * ap;
-        const int ga = fg == 0 ? (ap ? 5 : 0) : 2 * fg - 1 + ap;
-        float* const pf = sl + (int64_t)(ga * 6 + b) * g.KP * d.NcP;
+    for (int fi = 0; fi < 9; ++fi) {
+        float* const pf = sl + (int64_t)(9 * wave + fi) * g.KP * d.NcP;
 #pragma unroll
-        for (int mi = 0; mi < 3; ++mi)
+        for (int nj = 0; nj < 3; ++nj)
 #pragma unroll
-            for (int nj = 0; nj < 3; ++nj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ci = cib * 96 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    pf[(int64_t)ci * d.NcP + cob * 96 + nj * 32 + l31] = acc[(fi * 3 + mi) * 3 + nj][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int ci = cib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                pf[(int64_t)ci * d.NcP + cob * 96 + nj * 32 + l31] = acc[fi * 3 + nj][r];
+            }
     }
 }
 
@@ -379,7 +552,7 @@ static int wgrad43_plan(const adh_conv_desc* d, int nsplit, Wg43Args* a) {
     if (!enabled || !d) return 0;
     if (d->KH != 3 || d->KW != 3 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1) return 0;
     if (d->out_oy != 0 || d->out_ox != 0 || d->dy0 != -1 || d->dx0 != -1 || d->dstep_y != 1 || d->dstep_x != 1) return 0;
-    if (d->Cin % 96 != 0 || d->NcP % 96 != 0 || d->Cout != d->NcP || (d->in_cstride & 3) || (d->out_cstride & 3)) return 0;
+    if (d->Cin % 32 != 0 || d->NcP % 96 != 0 || d->Cout != d->NcP || (d->in_cstride & 3) || (d->out_cstride & 3)) return 0;
     if (d->in_cstride < d->Cin || d->out_cstride < d->Cout) return 0;
     if (d->VH != d->IH || d->VW != d->IW || d->VH != d->OH || d->VW != d->OW || (d->VH & 3) || (d->VW & 3)) return 0;
     if ((int64_t)d->N * (d->IH + 2) * d->IW * d->in_cstride >= (1ll << 30) || (int64_t)d->N * d->VH * d->VW * d->out_cstride >= (1ll << 30))
@@ -389,15 +562,21 @@ static int wgrad43_plan(const adh_conv_desc* d, int nsplit, Wg43Args* a) {
     a->S = d->N * a->TY * a->SX;
     a->nsplit = nsplit;
     a->ncob = d->NcP / 96;
-    a->ngroups = (d->Cin / 96) * a->ncob;
+    a->ngroups = (d->Cin / 32) * a->ncob;
     a->KP = d->Cin;
     return 1;
 }
 
-// workgroups per pixel split (channel-block pairs x three frequency groups); 0 = not this path
+// workgroups per pixel split (channel-block pairs); 0 = not this path
 extern "C" int adh_conv_wgrad_wino43_groups(const adh_conv_desc* d) {
     Wg43Args a;
-    return wgrad43_plan(d, 1, &a) ? 3 * a.ngroups : 0;
+    return wgrad43_plan(d, 1, &a) ? a.ngroups : 0;
+}
+
+// strips (4 x 16 output pixels) the pixel splits divide among themselves
+extern "C" int adh_conv_wgrad_wino43_strips(const adh_conv_desc* d) {
+    Wg43Args a;
+    return wgrad43_plan(d, 1, &a) ? a.S : 0;
 }
 
 extern "C" int adh_conv_wgrad_wino43(void* stream, const adh_conv_desc* d, float* slab, int nsplit) {
@@ -405,7 +584,7 @@ extern "C" int adh_conv_wgrad_wino43(void* stream, const adh_conv_desc* d, float
     Wg43Args a;
     if (!wgrad43_plan(d, nsplit, &a)) return ADH_E_UNSUPPORTED;
     if (((uintptr_t)d->in & 15) || ((uintptr_t)d->out & 15)) return ADH_E_ARG;
-    const int nblocks = ((nsplit + 7) / 8) * 3 * a.ngroups * 8;
+    const int nblocks = ((nsplit + 7) / 8) * a.ngroups * 8;
     hipStream_t s = (hipStream_t)stream;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_wino43_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);

@@ -25,9 +25,11 @@ BN_MOMENTUM = 0.1
 USE_WINOGRAD = os.environ.get("ADH_WINOGRAD", "1") != "0"
 # F(4x4,3x3) where it applies, else F(2x2,3x3): True / False, or "fwd" / "dgrad" to restrict it to one direction
 USE_WINO43 = {"0": False, "1": True}.get(os.environ.get("ADH_WINO43", "1"), os.environ.get("ADH_WINO43", "1"))
-# F(4x4,3x3)-domain weight gradient (conv_wgrad43.hip): correct and tested, but 15-25 % slower than the F(2x2,3x3)-domain
-# kernel as of round 1 -- opt-in
-USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "0") != "0"
+# F(4x4,3x3)-domain weight gradient (conv_wgrad43.hip, round-3 redesign: 32 x 96 channels x all 36 frequencies per workgroup):
+# 2.75 / 2.50 / 2.52 ms on the 96 / 192 / 384-channel layers against 3.10 / 2.78 / 2.79 for the F(2x2,3x3)-domain kernel
+#  -- the default where it applies (Cin % 32 == 0, Cout % 96 == 0); ADH_WINO43_WGRAD=0 falls back
+USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "1") != "0"
+W43_WGRAD_ROUNDS = int(os.environ.get("ADH_W43_WGRAD_ROUNDS", "4"))   # dev: rounds of workgroups the pixel splits may form
 USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"
 # Bit-packed ReLU mask for the residual BN layers (1 bit per element written by bn_apply, read by the two backward passes
 # instead of `out`): correct and tested, but measured SLOWER on MI355X (bench, ms/step: bn_apply 8.19 -> 8.47,
@@ -123,11 +125,11 @@ class BNState:
         self.num_batches_tracked = num_batches_tracked
 
 
-def _rows_nsplit(groups: int, ntiles: int, cus: int = 256) -> int:
+def _rows_nsplit(groups: int, ntiles: int, cus: int = 256, max_rounds: int = 4) -> int:
     """Pixel splits for the row-split weight-gradient kernel: one workgroup is resident per CU, so pick the
-    smallest nsplit (up to 4 rounds) whose groups*nsplit workgroups fill whole rounds of `cus` best."""
+    smallest nsplit (up to `max_rounds` rounds) whose groups*nsplit workgroups fill whole rounds of `cus` best."""
     best, best_eff = 1, 0.0
-    for ns in range(1, max(1, min(ntiles, 4 * cus // max(1, groups) + 1)) + 1):
+    for ns in range(1, max(1, min(ntiles, max_rounds * cus // max(1, groups) + 1)) + 1):
         total = groups * ns
         rounds = -(-total // cus)
         eff = total / (rounds * cus)
@@ -494,9 +496,9 @@ class Engine:
                 continue
             w43_groups = H.value("adh_conv_wgrad_wino43_groups", C.byref(d)) if (USE_WINOGRAD and USE_WINO43_WGRAD) else 0
             if w43_groups:
-                # 3x3 stride-1, channels in multiples of 96: accumulate in the F(4x4,3x3) domain (36 frequency slabs)
-                nstrips = x.N * (VH // 4) * ((VW // 4 + 5) // 6)
-                nsplit = _rows_nsplit(w43_groups, nstrips)
+                # 3x3 stride-1, Cin % 32 == 0, Cout % 96 == 0: accumulate in the F(4x4,3x3) domain (36 frequency slabs)
+                nstrips = H.value("adh_conv_wgrad_wino43_strips", C.byref(d))
+                nsplit = _rows_nsplit(w43_groups, nstrips, max_rounds=W43_WGRAD_ROUNDS)
                 while nsplit * 36 * KP * NcP * 4 > (1 << 30) and nsplit > 1:
                     nsplit //= 2
                 slab = self._f(nsplit * 36 * KP * NcP)

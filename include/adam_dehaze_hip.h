@@ -146,12 +146,13 @@ int adh_conv_wgrad_stem_slabs(const adh_conv_desc* d);
 int adh_conv_wgrad_stem(void* stream, const adh_conv_desc* d, float* slab, int NcP);
 
 /* Weight gradient of the same layers in the F(4x4,3x3) Winograd domain (conv_wgrad43.hip): 1/4 of the direct MFMA
- * work.  Needs Cin % 96 == 0, Cout % 96 == 0, H % 4 == 0, W % 4 == 0 (adh_conv_wgrad_wino43_groups(d) > 0: its value is
- * the number of workgroups per pixel split of each of the three launches, one per frequency-row pair).  d->in = x,
- * d->out = dL/dy as for adh_conv_wgrad.  slab: nsplit * 36 * Cin * NcP floats; adh_wgrad_reduce_wino43 sums the splits
+ * work.  Needs Cin % 32 == 0, Cout % 96 == 0, H % 4 == 0, W % 4 == 0 (adh_conv_wgrad_wino43_groups(d) > 0: its value is
+ * the number of workgroups per pixel split, one per 32 input x 96 output channels; adh_conv_wgrad_wino43_strips(d) = the
+ * 4 x 16-pixel strips the splits divide among themselves).  d->in = x, d->out = dL/dy as for adh_conv_wgrad.  slab: nsplit * 36 * Cin * NcP floats; adh_wgrad_reduce_wino43 sums the splits
  * (in place) and applies A'^T (.) A' with the 1/(N_a N_b) normalisation in double.  Replaces the weight half of ATen's
  * conv2d backward (/root/reference models/dehazing/base_model.py:11-13). */
 int adh_conv_wgrad_wino43_groups(const adh_conv_desc* d);
+int adh_conv_wgrad_wino43_strips(const adh_conv_desc* d);
 int adh_conv_wgrad_wino43(void* stream, const adh_conv_desc* d, float* slab, int nsplit);
 int adh_wgrad_reduce_wino43(void* stream, float* slab, int nsplit, int KP, int NcP, const adh_wlayout* L, float* dst,
                             int accumulate);

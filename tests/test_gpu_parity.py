@@ -401,11 +401,12 @@ def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, algo, monkeypatch):
                                            (2, 96, 48, 16, 64),     # partial last n-tile (output_conv.1 of the headline model)
                                            (1, 32, 16, 8, 32),
                                            (1, 96, 96, 4, 8), (2, 96, 192, 8, 24), (1, 192, 192, 12, 100),   # strips: ragged,
-                                           (1, 96, 96, 40, 200), (3, 96, 96, 16, 48)])                        # interior, exact
+                                           (1, 96, 96, 40, 200), (3, 96, 96, 16, 48),                         # interior, exact
+                                           (1, 32, 96, 24, 96), (2, 64, 192, 8, 36), (1, 384, 96, 8, 32)])    # F43: Cin % 32
 @pytest.mark.parametrize("algo", ["f23", "f43"])
 def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, algo, monkeypatch):
     """Winograd-domain weight gradients -- conv_wgrad_rows_kernel in Winograd mode + adh_wgrad_reduce_wino (F(2x2,3x3)
-    domain) and conv_wgrad_wino43_kernel + adh_wgrad_reduce_wino43 (F(4x4,3x3) domain; channel counts in multiples of 96,
+    domain) and conv_wgrad_wino43_kernel + adh_wgrad_reduce_wino43 (F(4x4,3x3) domain; Cin % 32 == 0 and Cout % 96 == 0,
     other shapes fall through to the former) -- against the direct row-split kernel and the fp64 definition, on tiles
     and strips with and without image borders."""
     import adam_dehaze_amd.engine as E
