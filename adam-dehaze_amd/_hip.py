@@ -104,6 +104,9 @@ _SIGNATURES = {
     "adh_bn_bwd_num_blocks": [i64, i32],
     "adh_bn_bwd_reduce": [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp, vp],
     "adh_bn_bwd_finalize": [vp, vp, i32, i32, f64, vp, vp, vp, vp, i32, vp],
+    "adh_bn_partial_sums": [vp, vp, i32, i32, i32, f64, vp],
+    "adh_bn_finalize_sums": [vp, vp, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp],
+    "adh_bn_bwd_finalize_sums": [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp],
     "adh_bn_bwd_apply": [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i64, i32, vp, vp],
     "adh_cbam_pool": [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "adh_cbam_pool_num_blocks": [i32],

@@ -79,6 +79,111 @@ extern "C" int adh_bn_finalize(void* stream, const float* partials, int nblk, in
     return adh_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Synchronised BatchNorm (data parallel, SURVEY 8e mode ii): the per-block partials are summed to sums[2][C] (+ the
+// element count in sums[2 C]) in fp64 on the device, the host all-reduces that small vector over the ranks (RCCL), and the
+// *_sums forms of the finalize kernels work from the global sums -- the statistics of the single-process reference's
+// BatchNorm2d over the whole batch (/root/reference models/dehazing/base_model.py:15-16).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn_partial_sums_kernel(const float* __restrict__ partials, int nblk, int pitch, int C,
+                                                               double count, double* __restrict__ sums) {
+    __shared__ double red[2][32][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
+    if (c < C) {
+        int b = ry;
+        for (; b + 32 < nblk; b += 64) {
+            s0 += (double)partials[((size_t)b * 2 + 0) * pitch + c];
+            q0 += (double)partials[((size_t)b * 2 + 1) * pitch + c];
+            s1 += (double)partials[((size_t)(b + 32) * 2 + 0) * pitch + c];
+            q1 += (double)partials[((size_t)(b + 32) * 2 + 1) * pitch + c];
+        }
+        for (; b < nblk; b += 32) {
+            s0 += (double)partials[((size_t)b * 2 + 0) * pitch + c];
+            q0 += (double)partials[((size_t)b * 2 + 1) * pitch + c];
+        }
+    }
+    red[0][ry][cx] = s0 + s1;
+    red[1][ry][cx] = q0 + q1;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        double S = 0.0, Q = 0.0;
+        for (int r = 0; r < 32; ++r) {
+            S += red[0][r][cx];
+            Q += red[1][r][cx];
+        }
+        sums[c] = S;
+        sums[C + c] = Q;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * C] = count;
+}
+
+extern "C" int adh_bn_partial_sums(void* stream, const float* partials, int nblk, int pitch, int C, double count, double* sums) {
+    if (!partials || !sums || nblk < 1 || C < 1 || pitch < C || count <= 0) return ADH_E_ARG;
+    hipLaunchKernelGGL(bn_partial_sums_kernel, dim3(adh_ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)stream, partials, nblk,
+                       pitch, C, count, sums);
+    return adh_check_launch();
+}
+
+__global__ void bn_finalize_sums_kernel(const double* __restrict__ sums, int C, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                                        float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                                        int64_t* num_batches_tracked) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double count = sums[2 * C];
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float gm = gamma ? gamma[c] : 1.f;
+    const float bt = beta ? beta[c] : 0.f;
+    scale[c] = (float)(gm * invstd);
+    shift[c] = (float)(bt - mean * gm * invstd);
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = (float)invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+}
+
+extern "C" int adh_bn_finalize_sums(void* stream, const double* sums, int C, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                                    float* save_mean, float* save_invstd, int64_t* num_batches_tracked) {
+    if (!sums || !scale || !shift || C < 1) return ADH_E_ARG;
+    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(adh_ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, sums, C, gamma,
+                       beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, num_batches_tracked);
+    return adh_check_launch();
+}
+
+// backward: d-gamma / d-beta stay the LOCAL sums (the gradient all-reduce averages them like every other parameter
+// gradient); the two means inside the input gradient come from the GLOBAL sums (torch.nn.SyncBatchNorm's backward)
+__global__ void bn_bwd_finalize_sums_kernel(const double* __restrict__ local_sums, const double* __restrict__ global_sums, int C,
+                                            const float* gamma, const float* invstd, float* dgamma, float* dbeta,
+                                            int accumulate, float* coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double count = global_sums[2 * C];
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)local_sums[C + c] : (float)local_sums[C + c];
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)local_sums[c] : (float)local_sums[c];
+    coef[0 * C + c] = (gamma ? gamma[c] : 1.f) * invstd[c];
+    coef[1 * C + c] = (float)(global_sums[c] / count);
+    coef[2 * C + c] = (float)(global_sums[C + c] / count);
+}
+
+extern "C" int adh_bn_bwd_finalize_sums(void* stream, const double* local_sums, const double* global_sums, int C,
+                                        const float* gamma, const float* invstd, float* dgamma, float* dbeta, int accumulate,
+                                        float* coef) {
+    if (!local_sums || !global_sums || !invstd || !coef || C < 1) return ADH_E_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3(adh_ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, local_sums,
+                       global_sums, C, gamma, invstd, dgamma, dbeta, accumulate, coef);
+    return adh_check_launch();
+}
+
 __global__ void bn_fold_eval_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
                                     float eps, const float* conv_bias, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

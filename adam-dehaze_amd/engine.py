@@ -73,6 +73,10 @@ def _layout_key(L: WLayout) -> tuple:
 # Test hook (tests/_util.py: kink_matched): when a dict, every fused conv(+BN)+ReLU op stores its post-activation output
 # under id(weight), so a test can replay the ReLU masks this implementation actually used in the float64 oracle.
 RELU_CAPTURE: Optional[Dict[int, torch.Tensor]] = None
+# Synchronised BatchNorm (parallel.GradientSynchronizer(sync_bn=True)): SYNC_BN(sums) all-reduces (SUM) the fp64 vector
+# [sum(C) | second row (C) | count] of one BatchNorm layer over the ranks, in place, ordered after the kernels enqueued so far
+# on the current stream; None = per-replica statistics.
+SYNC_BN: Optional[Callable[[torch.Tensor], None]] = None
 GRAD_SINK: Optional[Callable[[torch.Tensor], Optional[torch.Tensor]]] = None
 GRAD_READY: Optional[Callable[[torch.Tensor, torch.Tensor], None]] = None
 
@@ -610,9 +614,18 @@ class Engine:
             scale, shift = ss[0], ss[1]
             mean, invstd = self._f(Cout), self._f(Cout)
             NcP = _round_up(Cout, 32)
-            H.call("adh_bn_finalize", stats.data_ptr(), nblk, NcP, Cout, float(P), bn.weight.data_ptr(),
-                   bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), H.ptr(bn.num_batches_tracked))
+            if SYNC_BN is not None:
+                # statistics over the GLOBAL batch: local sums in fp64 -> all-reduce of 2 C + 1 doubles -> finalize
+                sums = torch.empty(2 * Cout + 1, device=self.device, dtype=torch.float64)
+                H.call("adh_bn_partial_sums", stats.data_ptr(), nblk, NcP, Cout, float(P), sums.data_ptr())
+                SYNC_BN(sums)
+                H.call("adh_bn_finalize_sums", sums.data_ptr(), Cout, bn.weight.data_ptr(), bn.bias.data_ptr(), BN_EPS,
+                       BN_MOMENTUM, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                       mean.data_ptr(), invstd.data_ptr(), H.ptr(bn.num_batches_tracked))
+            else:
+                H.call("adh_bn_finalize", stats.data_ptr(), nblk, NcP, Cout, float(P), bn.weight.data_ptr(),
+                       bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                       scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), H.ptr(bn.num_batches_tracked))
             # residual + ReLU (ResidualBlock tail): the backward ReLU mask cannot be recomputed from y alone; keep it as one
             # bit per element (1/32 of `out`) written by this pass instead of reading `out` twice in the backward pass
             mbits = None
@@ -674,8 +687,18 @@ class Engine:
             else:
                 dgamma, dbeta = self._f(C4), self._f(C4)
             coef = self._f(3, C4)
-            H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), bn.weight.data_ptr(),
-                   invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
+            if SYNC_BN is not None:
+                # d-gamma / d-beta: local sums (averaged with the other gradients); the means inside the input gradient:
+                # global sums (torch.nn.SyncBatchNorm's backward)
+                loc = torch.empty(2 * C4 + 1, device=self.device, dtype=torch.float64)
+                H.call("adh_bn_partial_sums", partial.data_ptr(), nblk, C4, C4, float(P), loc.data_ptr())
+                glob = loc.clone()
+                SYNC_BN(glob)
+                H.call("adh_bn_bwd_finalize_sums", loc.data_ptr(), glob.data_ptr(), C4, bn.weight.data_ptr(), invstd.data_ptr(),
+                       dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
+            else:
+                H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), bn.weight.data_ptr(),
+                       invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
             H.call("adh_bn_bwd_apply", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
                    y.stride(2), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), 1, g_y.data_ptr(), g_y.stride(2),
                    H.ptr(g_res), g_res.stride(2) if g_res is not None else 0, P, C4, mask_ss, H.ptr(mbits),

@@ -51,7 +51,12 @@ def _is_dist() -> bool:
 
 class GradientSynchronizer:
     def __init__(self, params: Iterable[torch.Tensor], world_size: int, bucket_bytes: int = 32 << 20,
-                 detect_unused: bool = False, rebuild: bool = True):
+                 detect_unused: bool = False, rebuild: bool = True, sync_bn: bool = False):
+        """`sync_bn=True` (SURVEY 8e mode ii): every train-mode BatchNorm layer all-reduces its [sum, sum of squares,
+        count] (forward) and [sum g, sum g*xhat, count] (backward) -- 2 C + 1 doubles -- so that statistics and gradients
+        are those of the single-process reference at the GLOBAL batch; ~70 small, sequentially dependent collectives per
+        CORUN-Complex forward pass (latency-bound: opt-in)."""
+        self.sync_bn = sync_bn
         seen, self.params = set(), []
         for p in params:
             if p.requires_grad and id(p) not in seen:
@@ -111,13 +116,27 @@ class GradientSynchronizer:
         """Route the engine's gradient buffers and grad-ready notifications through this synchronizer."""
         from . import engine as E
         E.GRAD_SINK, E.GRAD_READY = self._sink, self._on_ready
+        if self.sync_bn and self.world > 1:
+            E.SYNC_BN = self._sync_bn_all_reduce
         self._installed = True
 
     def uninstall(self):
         from . import engine as E
         if self._installed and E.GRAD_READY == self._on_ready:
             E.GRAD_SINK = E.GRAD_READY = None
+            E.SYNC_BN = None
         self._installed = False
+
+    @staticmethod
+    def _sync_bn_all_reduce(sums: torch.Tensor) -> None:
+        """SUM over the ranks, in place.  RCCL: enqueued behind the producing kernel of the current stream, the current stream
+        then waits for it (torch's synchronous-op semantics); gloo: through the host."""
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        else:
+            host = sums.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            sums.copy_(host)
 
     def _sink(self, p: torch.Tensor) -> Optional[torch.Tensor]:
         i = self.index.get(id(p))

@@ -67,6 +67,12 @@ class ReduceLROnPlateau:
         self.best, self.bad = sd["best"], sd["num_bad_epochs"]
 
 
+def _sync_bn(config) -> bool:
+    """Data-parallel BatchNorm mode: `parallel: {sync_bn: true}` in the config (or ADH_SYNC_BN=1) selects
+    synchronised statistics -- the single-process reference's semantics at the global batch; default: per-replica."""
+    return bool(config.get("parallel", {}).get("sync_bn", False)) or os.environ.get("ADH_SYNC_BN", "0") == "1"
+
+
 def _world_rank():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
 
@@ -104,7 +110,7 @@ def build_joint_system(config, world_size: int = 1, adam_duplicates: str = "sequ
     if world_size > 1:
         # a hard router leaves the branches a rank did not route to without gradients: agree on who produced what
         hard = config.get("routing", {}).get("type", "soft") == "hard"
-        sync = GradientSynchronizer(list(router.parameters()), world_size, detect_unused=hard)
+        sync = GradientSynchronizer(list(router.parameters()), world_size, detect_unused=hard, sync_bn=_sync_bn(config))
         sync.broadcast_parameters(router)
         sync.install()
     return {"classifier": classifier, "models": models, "router": router, "optimizer": optimizer,
@@ -462,7 +468,7 @@ def train_dehazing_model(config, intensity_level: str, train_loader=None, val_lo
     ck_dir = os.path.join(config["dehazing"]["checkpoint_dir"], intensity_level)
     sync = None
     if world > 1:
-        sync = GradientSynchronizer(list(model.parameters()), world)
+        sync = GradientSynchronizer(list(model.parameters()), world, sync_bn=_sync_bn(config))
         sync.broadcast_parameters(model)
         sync.install()
     start_epoch, best_val_psnr = 0, 0.0

@@ -209,6 +209,19 @@ int adh_bn_finalize(void* stream, const float* partials, int nblk, int NcP, int 
                     float* running_mean, float* running_var,
                     float* scale, float* shift, float* save_mean, float* save_invstd,
                     int64_t* num_batches_tracked /* optional: BatchNorm2d's int64 counter, incremented by 1 */);
+/* Synchronised BatchNorm under data parallelism (SURVEY 8e mode ii; reproduces the single-process reference's
+ * nn.BatchNorm2d over the GLOBAL batch, /root/reference models/dehazing/base_model.py:15-16).  adh_bn_partial_sums reduces
+ * partials[nblk][2][pitch] (the forward statistics of the conv epilogue, or adh_bn_bwd_reduce's output) to
+ * sums[0..C) = sum, sums[C..2C) = second row, sums[2C] = count, in fp64; the host all-reduces the 2C+1 doubles over the ranks;
+ * adh_bn_finalize_sums / adh_bn_bwd_finalize_sums are adh_bn_finalize / adh_bn_bwd_finalize working from such sums
+ * (backward: d-gamma / d-beta from the LOCAL sums, the input-gradient coefficients from the GLOBAL ones, as
+ * torch.nn.SyncBatchNorm does). */
+int adh_bn_partial_sums(void* stream, const float* partials, int nblk, int pitch, int C, double count, double* sums);
+int adh_bn_finalize_sums(void* stream, const double* sums, int C, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                         float* save_mean, float* save_invstd, int64_t* num_batches_tracked);
+int adh_bn_bwd_finalize_sums(void* stream, const double* local_sums, const double* global_sums, int C, const float* gamma,
+                             const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef);
 /* eval mode: scale/shift from running statistics */
 int adh_bn_fold_eval(void* stream, int C, const float* gamma, const float* beta,
                      const float* running_mean, const float* running_var, float eps,

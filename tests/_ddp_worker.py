@@ -29,7 +29,8 @@ def main():
     torch.manual_seed(100 + rank)            # replicas start DIFFERENT: the broadcast must fix that
     model = A.HighIntensityDehazeModel(base_channels=16).to(dev).train()
     params = list(model.parameters())
-    sync = GradientSynchronizer(params, world, bucket_bytes=64 << 10)
+    sync_bn = os.environ.get("ADH_DDP_SYNC_BN", "0") == "1"
+    sync = GradientSynchronizer(params, world, bucket_bytes=64 << 10, sync_bn=sync_bn)
     sync.broadcast_parameters(model)
     sync.install()
     opt = Adam(params, lr=1e-3, weight_decay=1e-4)
@@ -61,6 +62,7 @@ def main():
                                   else True for p in params)
             rec["bn"] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if "running" in k}
             rec["loss"] = float(loss)
+            rec["out"] = out.detach().cpu().clone()
         opt.step()
         # rank-dependent raw metric (rank 0 improves, rank 1 gets worse): only the rank-mean may drive the scheduler
         raw = (1.0 - 0.3 * step) if rank == 0 else (1.0 + 0.5 * step)

@@ -19,10 +19,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_training_step_matches_shardwise_oracle(tmp_path):
-    world = 2
-    port = 31000 + os.getpid() % 2000
-    env = dict(os.environ, ADH_WINOGRAD="0", HSA_ENABLE_IPC_MODE_LEGACY="0")   # direct kernels: reference summation order
+def _run_ranks(tmp_path, world, port_base, **extra_env):
+    """Start `world` fresh child processes (never a re-exec of this one) of tests/_ddp_worker.py and return their records."""
+    port = port_base + os.getpid() % 2000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_worker.py"), str(r), str(world), str(port),
                                str(tmp_path)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
@@ -36,7 +36,12 @@ def test_two_rank_training_step_matches_shardwise_oracle(tmp_path):
             raise
         outs.append(o.decode(errors="replace"))
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
-    recs = [torch.load(tmp_path / f"rank{r}.pt", map_location="cpu") for r in range(world)]
+    return [torch.load(tmp_path / f"rank{r}.pt", map_location="cpu") for r in range(world)]
+
+
+def test_two_rank_training_step_matches_shardwise_oracle(tmp_path):
+    world = 2
+    recs = _run_ranks(tmp_path, world, 31000, ADH_WINOGRAD="0")   # direct kernels: reference summation order
     # replicas were seeded differently and broadcast from rank 0
     for k, v in recs[0]["sd0"].items():
         assert torch.equal(v, recs[1]["sd0"][k]), k
@@ -80,3 +85,55 @@ def test_two_rank_training_step_matches_shardwise_oracle(tmp_path):
         assert recs[r]["order"][1] == recs[r]["order"][2] and recs[r]["order"][0] != recs[r]["order"][1]
         assert recs[r]["early"][1] >= recs[r]["nbuckets"][1] - 1 and recs[r]["early"][2] >= 1
     assert recs[0]["order"][1] == recs[1]["order"][1]
+
+
+@pytest.mark.parametrize("kernels", ["direct", "winograd"])
+def test_two_rank_sync_bn_matches_the_unsharded_reference(tmp_path, kernels):
+    """SURVEY 8e mode (ii), VERDICT r2 item 7: with `GradientSynchronizer(sync_bn=True)` every train-mode BatchNorm layer
+    all-reduces its [sum, sum of squares, count] (and [sum g, sum g*xhat] in the backward pass), so two ranks with two
+    images each reproduce the SINGLE-PROCESS reference on the unsharded 4-image batch (/root/reference
+    models/dehazing/base_model.py:15-16: BatchNorm2d spans the whole batch there): outputs of both shards (2e-4), BatchNorm
+    buffers (1e-5, identical on both ranks), loss, and every synchronized gradient against the float64 oracle of the global
+    L1 loss with the ranks' own ReLU masks replayed (gate: 3 x the fp32 reference's own distance + 3e-4).  Run with the direct
+    kernels and with the default Winograd kernels (the replica-BN test above pins ADH_WINOGRAD=0)."""
+    world = 2
+    recs = _run_ranks(tmp_path, world, 33000, ADH_DDP_SYNC_BN="1", **({"ADH_WINOGRAD": "0"} if kernels == "direct" else {}))
+    hazy, clear, _ = R.synthetic_batch(2 * world, 32, 48, seed=77)
+    masks = {k: torch.cat([recs[r]["masks"][k] for r in range(world)], dim=0) for k in recs[0]["masks"]}
+
+    def oracle(dtype):
+        sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in recs[0]["sd0"].items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+
+        def run():
+            out = R.high_forward(hazy.to(dtype), sd, training=True)
+            # each rank's loss is the L1 mean over its shard; the synchronizer averages the gradients: the global mean
+            loss = F.l1_loss(out, clear.to(dtype))
+            loss.backward()
+            return out.detach(), loss.detach()
+        out, loss = oracle_with_masks(run, masks)
+        return out, float(loss), sd
+    out32, loss32, sd32 = oracle(torch.float32)
+    out64, loss64, sd64 = oracle(torch.float64)
+    for r in range(world):
+        assert float((recs[r]["out"].double() - out64[2 * r:2 * r + 2]).abs().max()) < 2e-4, r
+    assert abs(0.5 * (recs[0]["loss"] + recs[1]["loss"]) - loss64) < 1e-5
+    for k, v in recs[0]["bn"].items():
+        assert torch.equal(v, recs[1]["bn"][k]), k                      # one set of statistics on every rank ...
+        assert float((v.double() - sd64[k]).abs().max()) < 1e-5, k      # ... the global batch's
+    bad = []
+    for k in recs[0]["grads"]:
+        assert torch.equal(recs[0]["grads"][k], recs[1]["grads"][k]), k
+        if k.startswith("decoder") and k.endswith(".0.bias"):
+            continue      # ConvTranspose bias feeding train-mode BN: true gradient 0
+        g64 = sd64[k].grad
+        scale = max(float(g64.abs().max()), 1e-8)
+        err_gpu = float((recs[0]["grads"][k].double() - g64).abs().max()) / scale
+        err_ref = float((sd32[k].grad.double() - g64).abs().max()) / scale
+        if not err_gpu <= 3 * err_ref + 3e-4:
+            bad.append((k, err_gpu, err_ref))
+    assert not bad, bad[:6]
+    for k, v in recs[0]["params"].items():
+        assert torch.equal(v, recs[1]["params"][k]), k

@@ -156,6 +156,21 @@ def _worker_agreements(rank, world, port, ret):
     got = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(got, flat)
     ok &= torch.equal(got[0], got[1])                             # ... are identical after the broadcast
+    # sync-BN hook (SURVEY 8e mode ii): installed only on request, sums the [sum | sumsq | count] vector over the ranks in
+    # place, removed by uninstall
+    from adam_dehaze_amd import engine as E
+    plain = GradientSynchronizer(list(m.parameters()), world)
+    plain.install()
+    ok &= E.SYNC_BN is None
+    plain.uninstall()
+    sb = GradientSynchronizer(list(m.parameters()), world, sync_bn=True)
+    sb.install()
+    ok &= E.SYNC_BN is not None
+    v = torch.tensor([1.0 + rank, 10.0 * (rank + 1), 8.0], dtype=torch.float64)
+    E.SYNC_BN(v)
+    ok &= torch.equal(v, torch.tensor([3.0, 30.0, 16.0], dtype=torch.float64))
+    sb.uninstall()
+    ok &= E.SYNC_BN is None and E.GRAD_READY is None
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
