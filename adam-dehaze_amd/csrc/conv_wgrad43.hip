@@ -36,10 +36,14 @@
 
 #ifndef G4_DBG
 #define G4_DBG 0   // dev builds: 1 = skip the transform, 4 = skip the contraction, 8 = stage only the first strip,
-                   // 16 = do not wait for the pieces (wrong results), 32 = pieces in one burst before the contraction
+                   // 16 = do not wait for the pieces (wrong results), 32 = pieces in one burst before the contraction,
+                   // 64 = every strip stages the same pixels, 128 / 256 = degenerate per-lane patterns (issue-cost probes)
 #endif
 #ifndef G4_STAGE_REGS
 #define G4_STAGE_REGS 0   // 1: raw tiles through registers (buffer_load_dwordx4 in steps 0..10, ds_write_b128 seven steps later) instead of LDS-DMA
+#endif
+#ifndef G4_OPS_AFTER_HOOK
+#define G4_OPS_AFTER_HOOK 0
 #endif
 #define G4_T 4                                    // tiles per strip
 #define G4_XROW 768                               // floats per raw x row: 24 slots x 32 channels (slot = col + col / 4)
@@ -87,9 +91,15 @@ __device__ __forceinline__ void g4_load_ops(g4_lds_vf vlane, float& a, float (&b
 template <int ST, typename Hook>
 __device__ __forceinline__ void g4_contract(f32x16 (&acc)[27], g4_lds_vf vlane, float (&a)[2], float (&b)[2][3], Hook&& hook) {
     if constexpr (ST < 18) {
+#if G4_OPS_AFTER_HOOK
+        g4_mfma<(ST / 2) * 3 + 0>(acc[(ST / 2) * 3 + 0], a[ST & 1], b[ST & 1][0]);
+        hook(std::integral_constant<int, ST>{});
+        if constexpr (ST + 1 < 18) g4_load_ops<ST + 1>(vlane, a[(ST + 1) & 1], b[(ST + 1) & 1]);
+#else
         if constexpr (ST + 1 < 18) g4_load_ops<ST + 1>(vlane, a[(ST + 1) & 1], b[(ST + 1) & 1]);
         g4_mfma<(ST / 2) * 3 + 0>(acc[(ST / 2) * 3 + 0], a[ST & 1], b[ST & 1][0]);
         hook(std::integral_constant<int, ST>{});
+#endif
         g4_mfma<(ST / 2) * 3 + 1>(acc[(ST / 2) * 3 + 1], a[ST & 1], b[ST & 1][1]);
         g4_mfma<(ST / 2) * 3 + 2>(acc[(ST / 2) * 3 + 2], a[ST & 1], b[ST & 1][2]);
         g4_contract<ST + 1>(acc, vlane, a, b, hook);
@@ -481,7 +491,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
             float oa[2], ob[2][3];
             g4_load_ops<0>(vlane, oa[0], ob[0]);
             if ((G4_DBG & 32) && inner) stage_interior(xb, gb);
-            const Pat pt = load_patterns();
+            Pat pt = load_patterns();
+            // dev probes of the piece issue cost (interior pieces only; results are wrong): every lane the same 16 bytes / one
+            // contiguous KB per piece, both inside the strip's own pixels
+            if (G4_DBG & 128) pt.g0 = pt.g1 = pt.g2 = pt.x0 = pt.x1 = pt.x2 = xcs;
+            if (G4_DBG & 256) pt.g0 = pt.g1 = pt.g2 = pt.x0 = pt.x1 = pt.x2 = xcs + (lane & 7) * 16 + (lane >> 3) * xcs;
             if constexpr (G4_STAGE_REGS) {
                 constexpr int LAG = 5;                       // steps between a load and its LDS write (5 x 192 MFMA cycles)
                 f32x4 stg[11];
