@@ -26,6 +26,7 @@
 // halo pixels beyond the image too.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef G32_DBG
 #define G32_DBG 0   // dev builds (timing only, wrong results): 1 = stage only the first region, 2 = skip the contraction
@@ -279,6 +280,337 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32_kernel(const adh_conv_des
         }
 }
 
+// =====================================================================================================================
+// Round 3: conv_wgrad32v2_kernel -- the same F(3x3,2x2)-domain gradient with the design of conv_wgrad_wino43_kernel
+// (conv_wgrad43.hip): the transformed operands go through LDS ONCE as V[16 frequencies][tile][64 ci | 96 co] and feed the
+// MFMAs by plain ds_read_b32, instead of being re-derived from the raw images in registers by every wave (31 VALU per 12
+// MFMAs in the MFMA stream, and 82 LDS-DMA pieces per 96 MFMAs and wave: the kernel above is bound by those, 0.41 of the
+// MFMA peak).  Workgroup = 64 input x 96 output channels x all 16 frequencies; wave w owns frequency row a = w: 4
+// frequencies x 2 x 3 channel tiles = 24 accumulator tiles (16 in AGPRs).  Strip = 8 tiles of 3x3 (3 rows x 24 pixels of the
+// class grid, halo 4 x 25): 16 contraction steps of 6 MFMAs; 55 LDS-DMA pieces per strip (13.75 per wave and 96 MFMAs), one
+// behind the first MFMA of steps 0..13; one-pass register transforms, thread = (tile, channel quad, frequency row),
+// 20 wave-rounds per strip (8 of x, 12 of dY), five per wave.  Conflict-free LDS images without padding: an x pixel is 256 B
+// (the 16 lanes of a ds_read_b128 group = its 16 quads), a dY pixel 384 B = 96 banks = 32 mod 64 (adjacent tiles, 3 pixels
+// apart, land in the other bank half).  Shapes: Cin % 64 == 0, Cout % 96 == 0 (ConvTranspose 384 -> 96 / 192, Conv2d k4 s2
+// 192 -> 384); everything else stays on the kernel above / the direct kernel.
+// =====================================================================================================================
+#ifndef H2_DBG
+#define H2_DBG 0   // dev builds (timing only): 1 = skip the transform, 4 = skip the contraction, 8 = stage only the first strip
+#endif
+#define H2_T 8
+#define H2_XROW (28 * 64)                         // floats per raw halo row: 28 pixel slots (25 used) x 64 channels
+#define H2_RAWX_F (4 * H2_XROW)                   //  7,168
+#define H2_GROW (24 * 96)                         // floats per raw dY row
+#define H2_RAWG_F (3 * H2_GROW)                   //  6,912
+#define H2_VPLANE (H2_T * 160)                    //  1,280 floats per frequency: [tile][64 ci | 96 co]
+#define H2_V_F (16 * H2_VPLANE)                   // 20,480
+#define H2_TAB_F (4 * 64)
+#define H2_LDS_BYTES ((H2_RAWX_F + H2_RAWG_F + H2_V_F + H2_TAB_F) * 4)   // 139,264 B
+
+struct Wg32v2Args {
+    int ymin, xmin, xps;
+    int S, SX, TY, nsplit, ngroups, ncob;
+    int cls, ncls;
+};
+
+template <int IDX>
+__device__ __forceinline__ void h2_mfma(f32x16& c, float a, float b) {
+    if constexpr (IDX < 16) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+typedef const volatile __attribute__((address_space(3))) float* h2_lds_vf;   // one ds_read_b32 per operand, 16-bit immediates
+// step ST = b * 4 + ks: frequency b of the wave's row, tile pair ks
+template <int ST>
+__device__ __forceinline__ void h2_load_ops(h2_lds_vf vlane, float (&a)[2], float (&b)[3]) {
+    h2_lds_vf p = vlane + (ST / 4) * H2_VPLANE + (ST % 4) * 320;
+    a[0] = p[0];
+    a[1] = p[32];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) b[j] = p[64 + 32 * j];
+}
+template <int ST, typename Hook>
+__device__ __forceinline__ void h2_contract(f32x16 (&acc)[24], h2_lds_vf vlane, float (&a)[2][2], float (&b)[2][3], Hook&& hook) {
+    if constexpr (ST < 16) {
+        if constexpr (ST + 1 < 16) h2_load_ops<ST + 1>(vlane, a[(ST + 1) & 1], b[(ST + 1) & 1]);
+        constexpr int B6 = (ST / 4) * 6;
+        h2_mfma<B6 + 0>(acc[B6 + 0], a[ST & 1][0], b[ST & 1][0]);
+        hook(std::integral_constant<int, ST>{});
+        h2_mfma<B6 + 1>(acc[B6 + 1], a[ST & 1][0], b[ST & 1][1]);
+        h2_mfma<B6 + 2>(acc[B6 + 2], a[ST & 1][0], b[ST & 1][2]);
+        h2_mfma<B6 + 3>(acc[B6 + 3], a[ST & 1][1], b[ST & 1][0]);
+        h2_mfma<B6 + 4>(acc[B6 + 4], a[ST & 1][1], b[ST & 1][1]);
+        h2_mfma<B6 + 5>(acc[B6 + 5], a[ST & 1][1], b[ST & 1][2]);
+        h2_contract<ST + 1>(acc, vlane, a, b, hook);
+    }
+}
+
+// x round: frequency row A of tiles 4 TH .. 4 TH + 3: row A of B^T d per patch column, then the column transform
+//   B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+template <int A, int TH>
+__device__ __forceinline__ void h2_x_round(const float* rawx, float* V, int lane, float m1) {
+    constexpr int rA = A == 0 ? 0 : (A == 2 ? 2 : 1), rB = A == 0 ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
+    const int q16 = lane & 15, tile = 4 * TH + (lane >> 4);
+    const float* s = rawx + 3 * tile * 64 + q16 * 4;
+    f32x4 r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 dA = *reinterpret_cast<const f32x4*>(s + rA * H2_XROW + c * 64);
+        const f32x4 dB = *reinterpret_cast<const f32x4*>(s + rB * H2_XROW + c * 64);
+        r[c] = A == 1 ? dA + dB : adh_pksub(dA, dB, m1);
+    }
+    float* dst = V + (4 * A) * H2_VPLANE + tile * 160 + q16 * 4;
+    *reinterpret_cast<f32x4*>(dst) = adh_pksub(r[0], r[2], m1);
+    *reinterpret_cast<f32x4*>(dst + 1 * H2_VPLANE) = r[1] + r[2];
+    *reinterpret_cast<f32x4*>(dst + 2 * H2_VPLANE) = adh_pksub(r[2], r[1], m1);
+    *reinterpret_cast<f32x4*>(dst + 3 * H2_VPLANE) = adh_pksub(r[1], r[3], m1);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// dY round: frequency row A, output-channel tile J, all 8 tiles: G' dY G'^T with G' = [[1,0,0],[1,1,1],[1,-1,1],[0,0,1]]
+// (rows / columns 1, 2 of G are these halved: the factor is applied by the reduce kernel)
+template <int A, int J>
+__device__ __forceinline__ void h2_g_round(const float* rawg, float* V, int lane, float m1) {
+    const int q8 = lane & 7, tile = lane >> 3;
+    const float* s = rawg + 3 * tile * 96 + J * 32 + q8 * 4;
+    f32x4 t[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if constexpr (A == 0) t[c] = *reinterpret_cast<const f32x4*>(s + c * 96);
+        else if constexpr (A == 3) t[c] = *reinterpret_cast<const f32x4*>(s + 2 * H2_GROW + c * 96);
+        else {
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(s + c * 96), y1 = *reinterpret_cast<const f32x4*>(s + H2_GROW + c * 96),
+                        y2 = *reinterpret_cast<const f32x4*>(s + 2 * H2_GROW + c * 96);
+            const f32x4 e = y0 + y2;
+            t[c] = A == 1 ? e + y1 : adh_pksub(e, y1, m1);
+        }
+    }
+    const f32x4 e = t[0] + t[2];
+    float* dst = V + (4 * A) * H2_VPLANE + tile * 160 + 64 + J * 32 + q8 * 4;
+    *reinterpret_cast<f32x4*>(dst) = t[0];
+    *reinterpret_cast<f32x4*>(dst + 1 * H2_VPLANE) = e + t[1];
+    *reinterpret_cast<f32x4*>(dst + 2 * H2_VPLANE) = adh_pksub(e, t[1], m1);
+    *reinterpret_cast<f32x4*>(dst + 3 * H2_VPLANE) = t[2];
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_desc d, const Wg32v2Args g, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // rawx | rawg | V | pattern table
+    const int bid = blockIdx.x;
+    const int q2 = bid >> 3;
+    const int grp = q2 % g.ngroups;
+    const int split = (q2 / g.ngroups) * 8 + (bid & 7);
+    if (split >= g.nsplit) return;
+    float* const rawx = smem;
+    float* const rawg = smem + H2_RAWX_F;
+    float* const V = rawg + H2_RAWG_F;
+    int* const tab = reinterpret_cast<int*>(V + H2_V_F);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+    const int cob = grp % g.ncob, cib = grp / g.ncob;
+    const int ci0 = cib * 64, co0 = cob * 96;
+
+    const int xcs = d.in_cstride * 4 * g.xps, gcs = d.out_cstride * 4 * d.out_sx;
+    const int xrs = d.IW * d.in_cstride * 4 * g.xps, grs = d.OW * d.out_cstride * 4 * d.out_sy;
+    const float* xbase = d.in + ((int64_t)g.ymin * d.IW + g.xmin) * d.in_cstride + ci0;
+    const float* gbase = d.out + ((int64_t)d.out_oy * d.OW + d.out_ox) * d.out_cstride + co0;
+    const int64_t ximg = (int64_t)d.IH * d.IW * d.in_cstride, gimg = (int64_t)d.OH * d.OW * d.out_cstride;
+    // per-lane global offsets of the pieces: x piece = 4 pixels x 16 quads; dY pieces k, k + 3 are 8 pixels apart
+    if (tid < 64) {
+        tab[tid] = (tid >> 4) * xcs + (tid & 15) * 16;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int b = 1024 * k + 16 * tid;
+            tab[(1 + k) * 64 + tid] = (b / 384) * gcs + (b % 384);
+        }
+    }
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_ptr_g32)smem;
+    const float m1 = adh_opaque(-1.f);
+
+    struct Pat { int x, g0, g1, g2; };
+    auto load_patterns = [&]() {
+        typedef const volatile __attribute__((address_space(3))) int* lds_vi;
+        lds_vi t = (lds_vi)(tab + lane);
+        Pat p;
+        p.x = t[0]; p.g0 = t[64]; p.g1 = t[128]; p.g2 = t[192];
+        return p;
+    };
+    struct Geom { __amdgpu_buffer_rsrc_t xr, gr; int vy0, vx0, iy0, ix0; unsigned xb, gb; bool interior; };
+    auto strip_geom = [&](int s) {
+        Geom t;
+        int r = s;
+        const int sx = r % g.SX;
+        r /= g.SX;
+        const int ty = r % g.TY;
+        const int n = r / g.TY;
+        t.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase + n * ximg), 0, 0x7fffffff, 0x00020000);
+        t.gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gbase + n * gimg), 0, 0x7fffffff, 0x00020000);
+        t.vy0 = ty * 3;
+        t.vx0 = sx * 24;
+        t.iy0 = t.vy0 * g.xps + g.ymin;
+        t.ix0 = t.vx0 * g.xps + g.xmin;
+        t.xb = __builtin_amdgcn_readfirstlane((unsigned)(t.vy0 * xrs + t.vx0 * xcs));
+        t.gb = __builtin_amdgcn_readfirstlane((unsigned)(t.vy0 * grs + t.vx0 * gcs));
+        t.interior = t.iy0 >= 0 && t.iy0 + 3 * g.xps < d.IH && t.ix0 >= 0 && t.ix0 + 27 * g.xps < d.IW &&
+                     t.vy0 + 3 <= d.VH && t.vx0 + 24 <= d.VW;
+        return t;
+    };
+    auto dma_x = [&](const Geom& t, const int row, const int pc, const int pat) {
+        const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(row * H2_XROW + pc * 256) * 4);
+        const unsigned so = __builtin_amdgcn_readfirstlane(t.xb + row * xrs + pc * 4 * xcs);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t.xr, (lds_void_ptr_g32)(uintptr_t)ldsa, 16, pat, so, 0, 0);
+    };
+    auto dma_g = [&](const Geom& t, const int row, const int k, const int pat) {
+        const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(H2_RAWX_F + row * H2_GROW + k * 256) * 4);
+        const unsigned so = __builtin_amdgcn_readfirstlane(t.gb + row * grs + (k / 3) * 8 * gcs);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t.gr, (lds_void_ptr_g32)(uintptr_t)ldsa, 16, pat, so, 0, 0);
+    };
+    // piece ST (0..13) of this wave: waves 0..2: dY row w pieces 0..5, x row w pieces 0..6, then x row 3 piece 5 / 6 (waves 0 / 1);
+    // wave 3: dY pieces 6..8 of rows 0..2, then x row 3 pieces 0..4.  dY pieces at steps 0..8 use pattern ST % 3 on every wave.
+    auto stage_piece = [&](auto stc, const Geom& t, const Pat& p) {
+        constexpr int ST = decltype(stc)::value;
+        const int gpat = ST % 3 == 0 ? p.g0 : (ST % 3 == 1 ? p.g1 : p.g2);
+        if constexpr (ST < 6) {
+            if (wave < 3) dma_g(t, wave, ST, gpat);
+            else dma_g(t, ST / 3, 6 + ST % 3, gpat);
+        } else if constexpr (ST < 9) {
+            if (wave < 3) dma_x(t, wave, ST - 6, p.x);
+            else dma_g(t, 2, 6 + ST % 3, gpat);
+        } else if constexpr (ST < 13) {
+            if (wave < 3) dma_x(t, wave, ST - 6, p.x);
+            else dma_x(t, 3, ST - 9, p.x);
+        } else if constexpr (ST == 13) {
+            if (wave == 0) dma_x(t, 3, 5, p.x);
+            else if (wave == 1) dma_x(t, 3, 6, p.x);
+            else if (wave == 3) dma_x(t, 3, 4, p.x);
+        }
+    };
+    auto stage_interior = [&](const Geom& t) {
+        const Pat p = load_patterns();
+        stage_piece(std::integral_constant<int, 0>{}, t, p);
+        stage_piece(std::integral_constant<int, 1>{}, t, p);
+        stage_piece(std::integral_constant<int, 2>{}, t, p);
+        stage_piece(std::integral_constant<int, 3>{}, t, p);
+        stage_piece(std::integral_constant<int, 4>{}, t, p);
+        stage_piece(std::integral_constant<int, 5>{}, t, p);
+        stage_piece(std::integral_constant<int, 6>{}, t, p);
+        stage_piece(std::integral_constant<int, 7>{}, t, p);
+        stage_piece(std::integral_constant<int, 8>{}, t, p);
+        stage_piece(std::integral_constant<int, 9>{}, t, p);
+        stage_piece(std::integral_constant<int, 10>{}, t, p);
+        stage_piece(std::integral_constant<int, 11>{}, t, p);
+        stage_piece(std::integral_constant<int, 12>{}, t, p);
+        stage_piece(std::integral_constant<int, 13>{}, t, p);
+    };
+    // border / ragged strip: zero both raw images, then load only what lies inside the image / the class grid
+    auto stage_border = [&](const int sb) {
+        const Geom t = strip_geom(sb);
+        int ln = lane, td = tid;
+        asm volatile("" : "+v"(ln), "+v"(td));        // keeps LICM from hoisting this rare path's lane predicates out of the loop
+        const Pat p = load_patterns();
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = td; i < (H2_RAWX_F + H2_RAWG_F) / 4; i += 256) *reinterpret_cast<f32x4*>(smem + i * 4) = z;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int row = wave;                         // x row w, 7 pieces
+            const int iy = t.iy0 + row * g.xps;
+#pragma unroll 1
+            for (int pc = 0; pc < 7; ++pc) {
+                const int c = pc * 4 + (ln >> 4);
+                const int ix = t.ix0 + c * g.xps;
+                if (c < 25 && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) dma_x(t, row, pc, p.x);
+            }
+        }
+        if (wave < 3) {                                   // dY row w, 9 pieces
+            const int row = wave;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int px = (1024 * (k % 3) + 16 * ln) / 384 + 8 * (k / 3);
+                if (t.vy0 + row < d.VH && t.vx0 + px < d.VW) dma_g(t, row, k, k % 3 == 0 ? p.g0 : (k % 3 == 1 ? p.g1 : p.g2));
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------ transform: 20 rounds, five per wave
+    auto transform = [&]() {
+        if (wave == 0) {
+            h2_x_round<0, 0>(rawx, V, lane, m1); h2_x_round<0, 1>(rawx, V, lane, m1);
+            h2_g_round<0, 0>(rawg, V, lane, m1); h2_g_round<1, 1>(rawg, V, lane, m1); h2_g_round<2, 2>(rawg, V, lane, m1);
+        } else if (wave == 1) {
+            h2_x_round<1, 0>(rawx, V, lane, m1); h2_x_round<1, 1>(rawx, V, lane, m1);
+            h2_g_round<1, 0>(rawg, V, lane, m1); h2_g_round<2, 1>(rawg, V, lane, m1); h2_g_round<3, 2>(rawg, V, lane, m1);
+        } else if (wave == 2) {
+            h2_x_round<2, 0>(rawx, V, lane, m1); h2_x_round<2, 1>(rawx, V, lane, m1);
+            h2_g_round<2, 0>(rawg, V, lane, m1); h2_g_round<3, 1>(rawg, V, lane, m1); h2_g_round<0, 2>(rawg, V, lane, m1);
+        } else {
+            h2_x_round<3, 0>(rawx, V, lane, m1); h2_x_round<3, 1>(rawx, V, lane, m1);
+            h2_g_round<3, 0>(rawg, V, lane, m1); h2_g_round<0, 1>(rawg, V, lane, m1); h2_g_round<1, 2>(rawg, V, lane, m1);
+        }
+    };
+
+    f32x16 acc[24];
+#pragma unroll
+    for (int t = 0; t < 24; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    h2_lds_vf const vlane = (h2_lds_vf)(V + (4 * wave) * H2_VPLANE + h * 160 + l31);
+
+    const int per = (g.S + g.nsplit - 1) / g.nsplit;
+    int s = split * per;
+    const int s_end = adh_min_i(s + per, g.S);
+    if (s < s_end) {
+        const Geom t = strip_geom(s);
+        if (t.interior) stage_interior(t);
+        else stage_border(s);
+    }
+#pragma unroll 1
+    while (s < s_end) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // strip s landed; every wave is past the previous contraction (V is free)
+        if (!(H2_DBG & 1)) transform();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // V complete, raw consumed: the next strip may land
+        const int sn = s + 1;
+        const bool more = sn < s_end && !(H2_DBG & 8);
+        Geom tn = strip_geom(more ? sn : s);
+        const bool inner = more && tn.interior;
+        if (!(H2_DBG & 4)) {
+            float oa[2][2], ob[2][3];
+            h2_load_ops<0>(vlane, oa[0], ob[0]);
+            const Pat pt = load_patterns();
+            h2_contract<0>(acc, vlane, oa, ob, [&](auto stc) {
+                if constexpr (decltype(stc)::value < 14) {
+                    if (inner) stage_piece(stc, tn, pt);
+                }
+            });
+        } else if (inner) {
+            stage_interior(tn);
+        }
+        if (more && !inner) stage_border(sn);
+        s = sn;
+    }
+
+    // partial result -> slab[split][cls][f = 4 * wave + b][KP][NcP]
+    const int KP = d.Cin;
+    float* sbase = slab + (((size_t)split * g.ncls + g.cls) * 16 + wave * 4) * KP * d.NcP;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float* base = sbase + ((size_t)b * KP + ci0 + 32 * m) * d.NcP + co0 + 32 * j + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    base[(size_t)i * d.NcP] = acc[(b * 2 + m) * 3 + j][r];
+                }
+            }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct Wg32Class {
     int ymin, xmin, xps;
@@ -286,6 +618,8 @@ struct Wg32Class {
 };                                   // rev: taps walk backwards, halo offset (hy, hx) belongs to tap (1 - hy, 1 - hx)
 struct Wg32Plan {
     int ncls, TN;
+    int v2;                          // conv_wgrad32v2_kernel (Cin % 64 == 0, Cout % 96 == 0)
+    int S, SX, TY, ncob;             // its strips (3 x 24 class-grid pixels) and output-channel groups
     Wg32Args base;
     Wg32Class cls[4];
 };
@@ -301,7 +635,9 @@ static int wgrad32_plan(const adh_conv_desc* d, int nsplit, Wg32Plan* p) {
     // bytes per pixel as the direct kernel stages, for 4/9 of the MFMAs): measured at the headline shapes, ConvTranspose
     // 384 -> 96 10.25 -> 8.4 ms, but Conv2d k4 s2 96 -> 192 5.2 -> 6.2 ms.  The four-class (k4 s2) form therefore stays on
     // the direct kernel unless forced.
-    if (mode < 2 && d->KH == 4) return 0;
+    static const bool v2_enabled = !(getenv("ADH_WGRAD32_V2") && getenv("ADH_WGRAD32_V2")[0] == '0');   // A/B switch
+    p->v2 = v2_enabled && d->Cin % 64 == 0 && d->NcP % 96 == 0 && d->Cout == d->NcP;
+    if (mode < 2 && d->KH == 4 && !p->v2) return 0;
     if (d->Cin % 32 != 0 || d->Cout % 4 != 0 || d->NcP != adh_round_up(d->Cout, 32)) return 0;
     if (d->in_cstride % 4 != 0 || d->out_cstride % 4 != 0) return 0;
     if (d->in_sy != d->in_sx || d->dstep_y != d->dstep_x || d->out_sy != d->out_sx) return 0;
@@ -318,6 +654,14 @@ static int wgrad32_plan(const adh_conv_desc* d, int nsplit, Wg32Plan* p) {
     b.nsplit = nsplit;
     b.nco_groups = d->NcP / (32 * p->TN);
     b.ngroups = (d->Cin / 32) * b.nco_groups;
+    if (p->v2) {
+        p->SX = adh_ceil_div(d->VW, 3 * H2_T);
+        p->TY = b.tiles_y;
+        p->S = p->SX * p->TY * d->N;
+        p->ncob = d->NcP / 96;
+        b.ngroups = (d->Cin / 64) * p->ncob;
+        b.ntiles = p->S;
+    }
     const int s = d->in_sy, ds = d->dstep_y;
     if (d->KH == 2 && d->KW == 2 && (ds == s || ds == -s) && (s == 1 || s == 2)) {
         p->ncls = 1;
@@ -373,6 +717,20 @@ extern "C" int adh_conv_wgrad_wino32(void* stream, const adh_conv_desc* d, float
     const int lds = 2 * (G32_XF + p.TN * G32_TH * G32_GROW) * 4;
     const int nblocks = ((nsplit + 7) / 8) * p.base.ngroups * 8;
     hipStream_t s = (hipStream_t)stream;
+    if (p.v2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad32v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        for (int c = 0; c < p.ncls; ++c) {
+            Wg32v2Args a;
+            a.ymin = p.cls[c].ymin; a.xmin = p.cls[c].xmin; a.xps = p.cls[c].xps;
+            a.S = p.S; a.SX = p.SX; a.TY = p.TY; a.nsplit = nsplit; a.ngroups = p.base.ngroups; a.ncob = p.ncob;
+            a.cls = c; a.ncls = p.ncls;
+            hipLaunchKernelGGL(conv_wgrad32v2_kernel, dim3(nblocks), dim3(256), H2_LDS_BYTES, s, *d, a, slab);
+            const int rc = adh_check_launch();
+            if (rc) return rc;
+        }
+        return ADH_OK;
+    }
     for (int c = 0; c < p.ncls; ++c) {
         Wg32Args a = p.base;
         a.ymin = p.cls[c].ymin;

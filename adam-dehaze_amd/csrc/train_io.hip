@@ -283,3 +283,75 @@ extern "C" int adh_ssim_gray(void* stream, const float* pred_nchw, const float* 
                        1.0 / ((double)(H - SSIM_WIN + 1) * (double)(W - SSIM_WIN + 1)), ssim);
     return adh_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Paired augmentation (/root/reference data/dataset.py:59-64,100-116): RandomHorizontalFlip, RandomVerticalFlip and
+// ColorJitter(brightness 0.1, contrast 0.1) applied to hazy / clear / dehazed with ONE seed per sample, so the three images
+// get the same flips and the same jitter factors.  torchvision semantics for float tensors: brightness = clamp(b * x, 0, 1),
+// contrast = clamp(c * x + (1 - c) * mean(gray(x)), 0, 1) with gray = 0.2989 R + 0.587 G + 0.114 B over the whole image,
+// in the order the sample's permutation puts them.  params[n] = {flip_h, flip_v, brightness_first, b, c} (host draws).
+// Two launches: the grayscale mean of the image the contrast step sees (fp64 two-stage sum), then one gather pass.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aug_gray_partial_kernel(const float* __restrict__ x, const float* __restrict__ params, int64_t HW,
+                                                               double* __restrict__ partial) {
+    const int n = blockIdx.y;
+    const float* p = params + n * 5;
+    const float b = p[2] != 0.f ? p[3] : 1.f;            // brightness comes first: the contrast step sees clamp(b * x)
+    const float* px = x + (int64_t)n * 3 * HW;
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        const float r = fminf(fmaxf(b * px[i], 0.f), 1.f), g = fminf(fmaxf(b * px[HW + i], 0.f), 1.f),
+                    bl = fminf(fmaxf(b * px[2 * HW + i], 0.f), 1.f);
+        acc += (double)(0.2989f * r + 0.587f * g + 0.114f * bl);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)n * gridDim.x + blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+__global__ __launch_bounds__(256) void aug_apply_kernel(const float* __restrict__ x, const float* __restrict__ params,
+                                                        const double* __restrict__ partial, int nblk, int H, int W,
+                                                        float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int64_t HW = (int64_t)H * W;
+    const float* p = params + n * 5;
+    const bool fh = p[0] != 0.f, fv = p[1] != 0.f, bfirst = p[2] != 0.f;
+    const float b = p[3], c = p[4];
+    double m = 0.0;
+    for (int i = 0; i < nblk; ++i) m += partial[(int64_t)n * nblk + i];     // same order in every thread: deterministic
+    const float mean = (float)(m / (double)HW);
+    const float* src = x + (int64_t)n * 3 * HW;
+    float* dst = out + (int64_t)n * 3 * HW;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i / W), xx = (int)(i - (int64_t)y * W);
+        const int64_t j = (int64_t)(fv ? H - 1 - y : y) * W + (fh ? W - 1 - xx : xx);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = src[ch * HW + j];
+            if (bfirst) {
+                v = fminf(fmaxf(b * v, 0.f), 1.f);
+                v = fminf(fmaxf(c * v + (1.f - c) * mean, 0.f), 1.f);
+            } else {
+                v = fminf(fmaxf(c * v + (1.f - c) * mean, 0.f), 1.f);
+                v = fminf(fmaxf(b * v, 0.f), 1.f);
+            }
+            dst[ch * HW + i] = v;
+        }
+    }
+}
+
+extern "C" int adh_augment_num_blocks(int64_t HW) { return adh_max_i(1, adh_min_i(adh_ceil_div(HW, 256 * 16), 256)); }
+
+extern "C" int adh_paired_augment(void* stream, const float* x_nchw, const float* params, int N, int H, int W, double* partial,
+                                  int nblk, float* out_nchw) {
+    if (!x_nchw || !params || !partial || !out_nchw || N < 1 || N > 65535 || H < 1 || W < 1) return ADH_E_ARG;
+    const int64_t HW = (int64_t)H * W;
+    if (nblk != adh_augment_num_blocks(HW) || x_nchw == out_nchw) return ADH_E_ARG;
+    hipLaunchKernelGGL(aug_gray_partial_kernel, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, x_nchw, params, HW, partial);
+    hipLaunchKernelGGL(aug_apply_kernel, dim3(adh_min_i(adh_ceil_div(HW, 256), 2048), N), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                       params, partial, nblk, H, W, out_nchw);
+    return adh_check_launch();
+}

@@ -64,8 +64,54 @@ def apply_random_fog(clear_img: torch.Tensor, intensity: Union[str, Sequence[str
     return out[0] if single else out
 
 
+def draw_augment_params(n: int, rng=None) -> torch.Tensor:
+    """[n, 5] float32 {flip_h, flip_v, brightness_first, b, c}: the random choices of the reference's training transform
+    (data/dataset.py:59-64: RandomHorizontalFlip, RandomVerticalFlip, ColorJitter(brightness=0.1, contrast=0.1)) for n
+    samples, drawn the way data/dataset.py:100-116 does: `seed = np.random.randint(2147483647)` per sample, then
+    `torch.manual_seed(seed)` before the transform of EACH of the sample's images -- so hazy / clear / dehazed get the same
+    choices, which is why one parameter row per sample suffices.  Draw order inside the transform (torchvision):
+    `torch.rand(1) < 0.5` (horizontal), `torch.rand(1) < 0.5` (vertical), `torch.randperm(4)` (order of brightness /
+    contrast / saturation / hue; the last two are off), `uniform(0.9, 1.1)` for brightness, then for contrast."""
+    rng = np.random if rng is None else rng
+    rows = []
+    for _ in range(n):
+        g = torch.Generator().manual_seed(int(rng.randint(2147483647)))
+        fh = float(torch.rand(1, generator=g) < 0.5)
+        fv = float(torch.rand(1, generator=g) < 0.5)
+        perm = torch.randperm(4, generator=g).tolist()
+        b = float(torch.empty(1).uniform_(0.9, 1.1, generator=g))
+        c = float(torch.empty(1).uniform_(0.9, 1.1, generator=g))
+        rows.append([fh, fv, float(perm.index(0) < perm.index(1)), b, c])
+    return torch.tensor(rows, dtype=torch.float32)
+
+
+def paired_augment(images: Sequence[torch.Tensor], params: Optional[torch.Tensor] = None, rng=None):
+    """Apply ONE set of per-sample choices (`draw_augment_params`) to every tensor of `images` ([N,3,H,W] float32 in
+    [0,1] on the GPU: hazy, clear, dehazed ...), on device.  Returns (list of augmented tensors, params)."""
+    x0 = images[0]
+    H.require_cuda(x0, "image batch")
+    N, Cc, Hh, Ww = x0.shape
+    if Cc != 3:
+        raise RuntimeError(f"expected [N,3,H,W], got {tuple(x0.shape)}")
+    if params is None:
+        params = draw_augment_params(N, rng)
+    pd = params.to(device=x0.device, dtype=torch.float32).contiguous()
+    nblk = H.value("adh_augment_num_blocks", Hh * Ww)
+    outs = []
+    for x in images:
+        if x.shape != x0.shape:
+            raise RuntimeError("paired images must have one shape")
+        H.require_cuda(x, "image batch")
+        x = x.contiguous()
+        partial = torch.empty(N * nblk, device=x.device, dtype=torch.float64)
+        out = torch.empty_like(x)
+        H.call("adh_paired_augment", x.data_ptr(), pd.data_ptr(), N, Hh, Ww, partial.data_ptr(), nblk, out.data_ptr())
+        outs.append(out)
+    return outs, params
+
+
 def synthetic_loader(batch_size: int, size, steps: int, seed: int = 42, rank: int = 0,
-                     device: Optional[torch.device] = None) -> Iterator[Dict]:
+                     device: Optional[torch.device] = None, augment: bool = False) -> Iterator[Dict]:
     """Foggy / clear pairs with the reference's fog model, generated on `device` (default cuda): low-pass random clear
     frames, labels uniform in {0,1,2}, (beta, A) from the label's range.  Batch dict keys as data/dataset.py:118-124
     ('dehazed' omitted: nothing on the path reads it)."""
@@ -80,5 +126,7 @@ def synthetic_loader(batch_size: int, size, steps: int, seed: int = 42, rank: in
         labels = torch.from_numpy(host.randint(0, 3, size=batch_size).astype(np.int64))
         beta, A = draw_fog_params([LEVEL_NAMES[int(i)] for i in labels], host)
         hazy = apply_fog(clear, beta, A)
+        if augment:     # the reference's train-split transform, same choices for both images of a pair
+            (hazy, clear), _ = paired_augment([hazy, clear], rng=host)
         yield {"hazy": hazy, "clear": clear, "intensity": labels.to(device),
                "name": [f"synthetic_{i}" for i in range(batch_size)]}

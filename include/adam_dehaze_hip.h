@@ -421,6 +421,14 @@ int adh_adam_chunk_elems(void);
 int adh_adam_multi(void* stream, const adh_adam_tensor* table_dev, const int32_t* chunks_dev, int nchunks, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, int dup_mode,
                    int max_repeats, int calls_since_upload);
+/* Paired augmentation on NCHW float images in [0,1] (/root/reference data/dataset.py:59-64,100-116: RandomHorizontalFlip,
+ * RandomVerticalFlip, ColorJitter(brightness 0.1, contrast 0.1) with one seed shared by hazy / clear / dehazed).
+ * params[n] = {flip_h, flip_v, brightness_first, b, c} (5 floats per image, drawn on the host in torchvision's order);
+ * brightness = clamp(b x), contrast = clamp(c x + (1 - c) mean(gray)), gray = 0.2989 R + 0.587 G + 0.114 B.
+ * partial: N * adh_augment_num_blocks(H * W) doubles of workspace.  out != x. */
+int adh_augment_num_blocks(int64_t HW);
+int adh_paired_augment(void* stream, const float* x_nchw, const float* params, int N, int H, int W, double* partial, int nblk,
+                       float* out_nchw);
 /* Synthetic fog on NCHW images, per-image beta / airlight: hazy = clip(clear*t + A*(1-t), 0, 1),
  * t = exp(-beta*(0.3 + 0.7*sqrt((x-0.5)^2 + (y-0.2)^2))) on the unit grid (utils/helpers.py:241-258, transmission in
  * float64 as numpy evaluates it). */

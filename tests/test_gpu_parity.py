@@ -438,6 +438,9 @@ def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, algo, monkey
     ("convT", 1, 384, 96, 16, 64),     # the headline up-sampling layer's channels
     ("convT", 2, 64, 48, 10, 40),      # transposed, partial last n-tile, ragged
     ("convT", 1, 32, 8, 7, 30),        # transposed, a single partial n-tile
+    ("conv", 2, 192, 96, 24, 100),     # conv_wgrad32v2_kernel (Cin % 64 == 0, Cout % 96 == 0): four classes, ragged strips
+    ("convT", 2, 128, 192, 11, 37),    # v2, two output-channel groups, ragged in both directions
+    ("convT", 1, 64, 96, 30, 96),      # v2, interior strips (class grid 30 x 96: 4 strips per row)
 ])
 def test_wino32_weight_gradient_matches_direct(kind, N, Ci, Co, Hh, Ww, monkeypatch):
     """F(3x3,2x2)-domain weight gradient of the 2x2-tap forms (conv_wgrad32_kernel + adh_wgrad_reduce_wino32) against the

@@ -48,6 +48,8 @@ def main():
         ("head192to96_full", 192, 96, 512, 1024, "conv", 3, 1, 1),
         ("down96to192", 96, 192, 512, 1024, "conv", 4, 2, 1),
         ("up384to96", 384, 96, 256, 512, "convT", 4, 2, 1),
+        ("down192to384", 192, 384, 256, 512, "conv", 4, 2, 1),
+        ("up384to192", 384, 192, 128, 256, "convT", 4, 2, 1),
         ("stem7x7", 8, 96, 512, 1024, "conv", 7, 1, 3),
     ]
     for name, Cin, Cout, Hh, Ww, kind, k, stride, pad in cases:
