@@ -36,6 +36,12 @@ class ConvDesc(C.Structure):
     ]
 
 
+class FpnLevels(C.Structure):
+    """struct adh_fpn_levels."""
+    _fields_ = [("f", C.c_void_p * 4), ("H", C.c_int32 * 4), ("W", C.c_int32 * 4), ("cs", C.c_int32 * 4), ("scale", C.c_float * 4),
+                ("nlevels", C.c_int32)]
+
+
 class AdamTensor(C.Structure):
     """struct adh_adam_tensor."""
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("step", i32), ("repeats", i32)]
@@ -151,6 +157,12 @@ _SIGNATURES = {
     "adh_rows_sum": [vp, vp, i32, i32, f32, vp, i32],
     "adh_adam_step": [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32],
     "adh_adam_chunk_elems": [],
+    "adh_upsample_nearest_add": [vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32],
+    "adh_rpn_decode": [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, f32, f32, vp, vp],
+    "adh_nms_words": [i32],
+    "adh_nms_sorted": [vp, vp, vp, i32, f32, vp, vp],
+    "adh_roi_align_fpn": [vp, vp, vp, i32, i32, vp],
+    "adh_box_postprocess": [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp],
     "adh_augment_num_blocks": [i64],
     "adh_paired_augment": [vp, vp, vp, i32, i32, i32, vp, i32, vp],
     "adh_adam_multi": [vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, i32, i32, i32],
@@ -174,7 +186,7 @@ _SIGNATURES = {
 _VALUE_FUNCS = {"adh_version", "adh_conv_wino_supported", "adh_conv_wino_num_blocks", "adh_conv_wino32_supported", "adh_conv_wino43_supported", "adh_conv_wino43_num_blocks",
                 "adh_conv_wino32_num_blocks", "adh_conv_wgrad_wino_groups", "adh_conv_wgrad_wino32_groups", "adh_conv_wgrad_wino32_classes", "adh_conv_wgrad_wino32_tiles", "adh_conv_wgrad_wino43_groups", "adh_conv_wgrad_wino43_strips", "adh_conv_wgrad_small_slabs", "adh_conv_wgrad_stem_slabs", "adh_conv_stem_num_blocks", "adh_conv_wgrad_slabs", "adh_conv_wgrad_groups", "adh_conv_lds_bytes", "adh_conv_num_blocks", "adh_bn_bwd_num_blocks",
                 "adh_cbam_pool_num_blocks", "adh_cbam_bwd_b_num_blocks", "adh_head_blend_bwd_num_blocks",
-                "adh_reduce_num_blocks", "adh_lpips_layer_num_blocks", "adh_adam_chunk_elems", "adh_augment_num_blocks", "adh_psnr_num_blocks", "adh_cbam_bwd_d_scratch_floats",
+                "adh_reduce_num_blocks", "adh_lpips_layer_num_blocks", "adh_adam_chunk_elems", "adh_nms_words", "adh_augment_num_blocks", "adh_psnr_num_blocks", "adh_cbam_bwd_d_scratch_floats",
                 "adh_ssim_num_blocks"}
 
 _ERRORS = {-1: "ADH_E_ARG (bad argument: shape / alignment / null pointer)",

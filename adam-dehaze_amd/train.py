@@ -574,3 +574,61 @@ def evaluate_joint_model(config, test_loader=None, steps: int = 2, use_lpips: bo
     if world > 1:
         _barrier()
     return results
+
+
+def evaluate_detection(config, test_loader=None, steps: int = 1, score_threshold: float = 0.5):
+    """Detection half of evaluation/evaluate.py:179-383 on device: the detector on the hazy frames and on the routed (dehazed)
+    frames, detections with score > 0.5 (evaluate.py:327,343) converted to COCO [x, y, w, h] and counted per intensity category;
+    saved as `<evaluation.results_dir>/detection_results.json`.  COCO mAP itself (evaluation/metrics.py:126-270) needs
+    pycocotools and an annotation file, neither of which exists here: the detections are what COCOeval would be fed."""
+    import json
+    from .detection import create_detection_model, create_integrated_system, filter_detections
+    from .metrics import CATEGORY_BY_LABEL
+    world, rank = _world_rank()
+    if world > 1 and rank != 0:
+        _barrier()
+        return None
+    system = build_joint_system(config, 1)
+    dev = system["device"]
+    cfg = dict(config)
+    cfg.setdefault("detection", {"model": "faster_rcnn_resnet50_fpn", "pretrained": False})
+    detector = create_detection_model(cfg).to(dev).eval()
+    system["classifier"].eval()
+    for m in system["models"].values():
+        m.eval()
+    router = system["router"].eval()
+
+    class _Routed(torch.nn.Module):        # evaluate.py:262-286 process_batch: classifier -> router
+        def forward(self, images):
+            logits, _ = system["classifier"](images)
+            return router(images, logits)
+    integrated = create_integrated_system(_Routed(), detector)
+    if test_loader is None:
+        _warn_synthetic(config, "evaluate_detection", rank)
+        test_loader = synthetic_loader(config["dataset"]["batch_size"], config["dataset"]["img_size"], steps,
+                                       seed=config["seed"] + 910000, rank=rank, device=dev)
+    counts = {"hazy": {}, "dehazed": {}}
+    records = []
+    with torch.no_grad():
+        for batch in test_loader:
+            hazy = batch["hazy"].to(dev)
+            hazy_dets = filter_detections(detector(hazy), score_threshold)
+            dehazed_raw, _ = integrated(hazy)
+            dehazed_dets = filter_detections(dehazed_raw, score_threshold)
+            cats = [CATEGORY_BY_LABEL.get(int(i), "high_intensity") for i in batch["intensity"].tolist()]
+            for i, cat in enumerate(cats):
+                for tag, dets in (("hazy", hazy_dets), ("dehazed", dehazed_dets)):
+                    n = int(dets[i]["scores"].numel())
+                    counts[tag][cat] = counts[tag].get(cat, 0) + n
+                    for b, l, sc in zip(dets[i]["boxes_xywh"].tolist(), dets[i]["labels"].tolist(), dets[i]["scores"].tolist()):
+                        records.append({"source": tag, "image_id": batch["name"][i], "category_id": int(l),
+                                        "bbox": [float(v) for v in b], "score": float(sc), "intensity": cat})
+    out_dir = config.get("evaluation", {}).get("results_dir", "results")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "detection_results.json"), "w") as f:
+        json.dump({"score_threshold": score_threshold, "counts": counts, "detections": records}, f, indent=1)
+    print(f"Detections with score > {score_threshold}: hazy {counts['hazy']}, dehazed {counts['dehazed']} "
+          "(COCO mAP needs pycocotools + annotations: not available in this build)")
+    if world > 1:
+        _barrier()
+    return counts

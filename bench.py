@@ -190,10 +190,11 @@ def other_workloads(args, rank, world, device):
                 out, _ = router(hazy, labels)
             return out.sum()
         desc = "HDEN DenseNet121 classify + hard route (all-low labels) -> CORUN-Light forward (eval)"
-    elif wl in ("complex_eval", "config5"):   # eval-mode forward (config5: 1024x2048 frames, 4 per GPU)
+    elif wl in ("complex_eval", "config5", "config5_dehaze"):   # eval-mode forward (config5: 1024x2048 frames, 4 per GPU)
         model = A.HighIntensityDehazeModel().to(device).train()
-        hh, ww = (1024, 2048) if wl == "config5" else (args.height, args.width)
-        bs = 4 if wl == "config5" else bs
+        c5 = wl.startswith("config5")
+        hh, ww = (1024, 2048) if c5 else (args.height, args.width)
+        bs = 4 if c5 else bs
         hazy, _ = synthetic_batch(bs, hh, ww, seed=42 + rank)
         hazy = hazy.to(device)
         with torch.no_grad():
@@ -201,10 +202,20 @@ def other_workloads(args, rank, world, device):
         model.eval()
         args.height, args.width = hh, ww
 
+        detector = None
+        if wl == "config5":      # BASELINE config 5 end to end: dehaze -> detect (models/detection.py:73-125; random-init Faster R-CNN R50-FPN)
+            from adam_dehaze_amd.detection import DetectionModel, IMAGE_MEAN, IMAGE_STD
+            detector = DetectionModel(num_classes=91, pretrained=False).to(device).eval()
+
         def step():
             with torch.no_grad():
-                return model(hazy).sum()
-        desc = "CORUN-Complex eval-mode forward (BN folded into the conv epilogues)"
+                out = model(hazy)
+                if detector is None:
+                    return out.sum()
+                dets = detector(out, None, pre_affine=(IMAGE_MEAN, IMAGE_STD))
+                return out.sum() + sum(d["scores"].sum() for d in dets)
+        desc = "CORUN-Complex eval-mode forward (BN folded into the conv epilogues)" + \
+            (" -> Faster R-CNN ResNet-50 FPN detect (800 x 1333 transform, random-init weights: no mAP)" if detector is not None else "")
     elif wl == "config3" or wl == "complex_fullloss":
         model = (A.MediumIntensityDehazeModel() if wl == "config3" else A.HighIntensityDehazeModel()).to(device).train()
         crit = DehazingLoss().to(device)
@@ -382,7 +393,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forward-eval", action="store_true")
     ap.add_argument("--workload", default="complex",
-                    choices=["complex", "complex_fullloss", "complex_eval", "config2", "config3", "config4", "config5"],
+                    choices=["complex", "complex_fullloss", "complex_eval", "config2", "config3", "config4", "config5", "config5_dehaze"],
                     help="complex = headline (BASELINE.json metric); config2/3/4 = the other BASELINE.json configs")
     ap.add_argument("--no-adam", action="store_true")
     args = ap.parse_args()

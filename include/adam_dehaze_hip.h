@@ -421,6 +421,36 @@ int adh_adam_chunk_elems(void);
 int adh_adam_multi(void* stream, const adh_adam_tensor* table_dev, const int32_t* chunks_dev, int nchunks, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, int dup_mode,
                    int max_repeats, int calls_since_upload);
+/* ---- detector stage (csrc/detect.hip): what torchvision's Faster R-CNN -- the detector
+ * /root/reference models/detection.py:23-29 instantiates, consumed by evaluation/evaluate.py:288-344 -- does between its
+ * convolutions.  torchvision is a third-party dependency absent from /root/reference: the algorithms follow its published
+ * source (models/detection/{rpn,roi_heads,_utils,anchor_utils}.py, ops/{poolers,roi_align,boxes}.py). --------------------- */
+/* FPN top-down merge: lateral[n,y,x,:] += top[n, nearest(y), nearest(x), :] (F.interpolate(mode="nearest") + add). */
+int adh_upsample_nearest_add(void* stream, const float* top, int top_cs, int th, int tw, float* lateral, int lat_cs, int N,
+                             int H, int W, int C);
+/* RPN level: anchors (base_anchors[A][4] shifted by the strides, position major / anchor minor), BoxCoder(1,1,1,1).decode,
+ * clip to the image.  cls [N,H,W,>=A], reg [N,H,W,>=4A] -> boxes [N,H*W*A,4], logits [N,H*W*A]. */
+int adh_rpn_decode(void* stream, const float* cls, int cls_cs, const float* reg, int reg_cs, int N, int H, int W, int A,
+                   int stride_h, int stride_w, const float* base_anchors, float img_h, float img_w, float* boxes, float* logits);
+/* Grouped NMS (torchvision.ops.batched_nms): boxes [M,4] sorted by descending score, group [M]; keep[i] = 1 if box i survives.
+ * mask_workspace: M * adh_nms_words(M) uint64.  M <= 16384. */
+int adh_nms_words(int M);
+int adh_nms_sorted(void* stream, const float* boxes, const int32_t* group, int M, float iou_threshold, void* mask_workspace,
+                   int32_t* keep);
+/* MultiScaleRoIAlign (7x7, sampling_ratio 2, aligned = False) over up to four NHWC pyramid levels; rois [R,5] = (image, x1, y1,
+ * x2, y2); out [R][C*49] channel-major (torch's flatten(1) of [R,C,7,7]). */
+typedef struct adh_fpn_levels {
+    const float* f[4];
+    int32_t H[4], W[4], cs[4];
+    float scale[4];
+    int32_t nlevels;
+} adh_fpn_levels;
+int adh_roi_align_fpn(void* stream, const adh_fpn_levels* levels, const float* rois, int R, int C, float* out);
+/* Box head post-processing up to the NMS: softmax, BoxCoder(10,10,5,5).decode per foreground class, clip, validity
+ * (score > thresh, w and h >= min_size).  -> boxes [R,NC-1,4], scores [R,NC-1], valid [R,NC-1]. */
+int adh_box_postprocess(void* stream, const float* logits, int l_cs, const float* deltas, int d_cs, const float* props,
+                        const float* img_hw, const int32_t* img, int R, int NC, float score_thresh, float min_size, float* boxes,
+                        float* scores, int32_t* valid);
 /* Paired augmentation on NCHW float images in [0,1] (/root/reference data/dataset.py:59-64,100-116: RandomHorizontalFlip,
  * RandomVerticalFlip, ColorJitter(brightness 0.1, contrast 0.1) with one seed shared by hazy / clear / dehazed).
  * params[n] = {flip_h, flip_v, brightness_first, b, c} (5 floats per image, drawn on the host in torchvision's order);

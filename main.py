@@ -101,13 +101,14 @@ def main():
             T.train_dehazing_model(config, level, epochs=args.epochs or 30, resume=resume_for(level))
         print("\n===== Step 3: Training Joint Model =====")
         T.train_joint_model(config, epochs=args.epochs, resume=resume_for("joint"))
-        print("\n===== Step 4: Evaluation (image quality; the detection half needs torchvision detection weights) =====")
+        print("\n===== Step 4: Evaluation (image quality + detections on hazy / dehazed frames) =====")
         T.evaluate_joint_model(config)
+        T.evaluate_detection(config)
     elif args.mode == "evaluate":
         # evaluate.py:464-540 runs image-quality evaluation of the joint model, then object detection on dehazed frames;
         # the detector stage needs torchvision detection weights that are not in this image
         T.evaluate_joint_model(config)
-        print("object-detection evaluation (models/detection.py) is outside this build's scope: skipped")
+        T.evaluate_detection(config)       # detector on hazy vs dehazed frames (evaluate.py:288-344); mAP needs pycocotools + annotations
     elif args.mode == "demo":
         system = T.build_joint_system(config)
         system["router"].eval()

@@ -29,7 +29,8 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 _CTYPE = {"void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int32_t*": ctypes.c_void_p, "int64_t*": ctypes.c_void_p,
           "int": ctypes.c_int32, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
-          "double": ctypes.c_double, "double*": ctypes.c_void_p, "uint8_t*": ctypes.c_void_p, "adh_adam_tensor*": ctypes.c_void_p}
+          "double": ctypes.c_double, "double*": ctypes.c_void_p, "uint8_t*": ctypes.c_void_p, "adh_adam_tensor*": ctypes.c_void_p,
+          "adh_fpn_levels*": ctypes.c_void_p}
 
 
 def test_ctypes_signatures_match_header():
