@@ -444,6 +444,37 @@ def test_explicit_resume_file_goes_to_the_stage_that_wrote_it(tmp_path):
         T.checkpoint_stage(str(tmp_path / "junk.pth"), cfg)
 
 
+def test_detector_surface_and_torchvision_key_names():
+    """`models.detection` keeps the reference's names (models/detection.py:7-140) and the detector's parameters carry
+    torchvision's fasterrcnn_resnet50_fpn state_dict keys (v0.13 layout) under `model.`, so a real checkpoint loads where one
+    exists.  Spot-checked key names and shapes; the unsupported variants of the reference's switch raise ValueError."""
+    import warnings
+    import models.detection as MD
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = MD.create_detection_model({"detection": {"model": "faster_rcnn_resnet50_fpn", "pretrained": True}})
+    assert any("RANDOMLY" in str(x.message) for x in w)
+    sd = m.state_dict()
+    want = {"model.backbone.body.conv1.weight": (64, 3, 7, 7), "model.backbone.body.bn1.running_var": (64,),
+            "model.backbone.body.layer1.0.downsample.0.weight": (256, 64, 1, 1), "model.backbone.body.layer2.0.conv2.weight": (128, 128, 3, 3),
+            "model.backbone.body.layer4.2.bn3.weight": (2048,), "model.backbone.fpn.inner_blocks.3.0.weight": (256, 2048, 1, 1),
+            "model.backbone.fpn.layer_blocks.0.0.bias": (256,), "model.rpn.head.conv.0.0.weight": (256, 256, 3, 3),
+            "model.rpn.head.cls_logits.weight": (3, 256, 1, 1), "model.rpn.head.bbox_pred.bias": (12,),
+            "model.roi_heads.box_head.fc6.weight": (1024, 12544), "model.roi_heads.box_predictor.cls_score.weight": (91, 1024),
+            "model.roi_heads.box_predictor.bbox_pred.weight": (364, 1024)}
+    for k, shp in want.items():
+        assert k in sd and tuple(sd[k].shape) == shp, k
+    assert not any("num_batches_tracked" in k for k in sd)            # FrozenBatchNorm2d has none
+    assert len(sd) == 295 and all(not p.requires_grad for p in m.parameters())
+    assert isinstance(MD.create_integrated_system(torch.nn.Identity(), m), MD.IntegratedDetectionSystem)
+    for bad in ("faster_rcnn_mobilenet_v3_large_fpn", "mask_rcnn_resnet50_fpn", "yolov8n"):
+        with pytest.raises(ValueError):
+            MD.DetectionModel(model_name=bad, pretrained=False)
+    from adam_dehaze_amd.detection import base_anchors, resized_size
+    assert base_anchors(32).tolist() == [[-23.0, -11.0, 23.0, 11.0], [-16.0, -16.0, 16.0, 16.0], [-11.0, -23.0, 11.0, 23.0]]
+    assert resized_size(512, 1024, 800, 1333) == (666, 1333) and resized_size(512, 512, 800, 1333) == (800, 800)
+
+
 def test_loss_extractor_warnings_and_weight_loaders():
     """the VGG16 / LPIPS extractors start randomly initialised -- say so once; torchvision / lpips checkpoints
     load through key-remapping helpers (`features.{i}.*` -> `model.{i}.*`; `features.{i}.*` + `lin{k}.model.1.weight` ->

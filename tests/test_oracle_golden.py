@@ -274,3 +274,46 @@ def test_fullwidth_default_models_vs_reference_held_outputs(name, fwd, ctor):
     assert max_abs(out[0, :, 100:108, 100:108], rec[name + ".out_patch"]) < TOL
     assert abs(float(out.double().mean()) - float(rec[name + ".out_mean"])) < 1e-7
     assert abs(float(out.abs().max()) - float(rec[name + ".out_absmax"])) < TOL
+
+
+def test_detector_restatement_properties():
+    """The detector oracle is UNPINNED (torchvision absent): first-principles checks of the two pieces whose definitions are
+    easy to get subtly wrong.  RoIAlign of a constant map is the constant, and of the ramp f(y, x) = x the bin centres'
+    x (bilinear interpolation is exact on linear functions; 2 x 2 samples are symmetric about the bin centre).  Grouped
+    NMS: kept boxes of one group overlap by at most the threshold, and every dropped box overlaps a kept box of its group
+    with a higher score by more than the threshold."""
+    feat = torch.zeros(1, 2, 20, 30)
+    feat[0, 0] = 3.5
+    feat[0, 1] = torch.arange(30.0).view(1, 30).expand(20, 30)
+    rois = torch.tensor([[0.0, 4.0, 3.0, 18.0, 15.0], [0.0, 8.0, 8.0, 29.0, 19.0]])       # feature-map units at scale 1
+    out = R.det_roi_align(feat, rois, 1.0)
+    assert float((out[:, 0] - 3.5).abs().max()) < 1e-6
+    for r in range(2):
+        x1, x2 = float(rois[r, 1]), float(rois[r, 3])
+        centres = x1 + (torch.arange(7.0) + 0.5) * (x2 - x1) / 7
+        assert float((out[r, 1] - centres.view(1, 7)).abs().max()) < 1e-5
+    g = torch.Generator().manual_seed(4)
+    c = torch.rand(200, 2, generator=g) * 100
+    boxes = torch.cat([c, c + torch.rand(200, 2, generator=g) * 40 + 1], dim=1)
+    scores, groups = torch.rand(200, generator=g), torch.randint(0, 3, (200,), generator=g)
+    keep = R.det_nms(boxes, scores, groups, 0.4)
+    kept = set(keep.tolist())
+
+    def iou(i, j):
+        a, b = boxes[i], boxes[j]
+        iw = max(0.0, float(min(a[2], b[2]) - max(a[0], b[0])))
+        ih = max(0.0, float(min(a[3], b[3]) - max(a[1], b[1])))
+        inter = iw * ih
+        return inter / (float((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1])) - inter)
+    assert all(scores[keep[i]] >= scores[keep[i + 1]] for i in range(len(keep) - 1))
+    for i in kept:
+        for j in kept:
+            if i < j and groups[i] == groups[j]:
+                assert iou(i, j) <= 0.4
+    for i in set(range(200)) - kept:
+        assert any(groups[i] == groups[j] and scores[j] >= scores[i] and iou(i, j) > 0.4 for j in kept)
+    # anchors, decode: a zero delta returns the anchor; the size clamp holds
+    a = torch.tensor([[10.0, 20.0, 50.0, 80.0]])
+    assert torch.allclose(R.det_decode(torch.zeros(1, 4), a, (1.0, 1.0, 1.0, 1.0)), a)
+    big = R.det_decode(torch.tensor([[0.0, 0.0, 100.0, 100.0]]), a, (1.0, 1.0, 1.0, 1.0))
+    assert abs(float(big[0, 2] - big[0, 0]) - 40.0 * 1000.0 / 16) < 1e-2
