@@ -42,6 +42,9 @@
 #ifndef G4_STAGE_REGS
 #define G4_STAGE_REGS 0   // 1: raw tiles through registers (buffer_load_dwordx4 in steps 0..10, ds_write_b128 seven steps later) instead of LDS-DMA
 #endif
+#ifndef G4_GLOBAL_DMA
+#define G4_GLOBAL_DMA 0   // 1: global_load_lds_dwordx4 pieces: 52 vs 107 cycles of issue per piece in isolation (tools/micro/dma_cost.hip), no difference in this kernel (2.81 vs 2.81 ms); 0: buffer_load ... lds (range-checked)
+#endif
 #ifndef G4_OPS_AFTER_HOOK
 #define G4_OPS_AFTER_HOOK 0
 #endif
@@ -315,6 +318,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
         const_cast<char*>(reinterpret_cast<const char*>(d.in) - (int64_t)(d.IW + 1) * xcs), 0, 0xffffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.out), 0, 0xffffffff, 0x00020000);
     const unsigned xrow = (unsigned)d.IW * xcs, grow = (unsigned)d.VW * gcs;
+    typedef __attribute__((address_space(1))) void* g4_gptr;
+    const char* const xbase_c = reinterpret_cast<const char*>(d.in) - (int64_t)(d.IW + 1) * xcs;
+    const char* const gbase_c = reinterpret_cast<const char*>(d.out);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_ptr5)lds;     // 32-bit LDS address of the dynamic segment
     // LDS destination (M0) and scalar offset go through readfirstlane at the point of use: hipcc otherwise carries some
     // of these wave-uniform values in VGPRs across the loop and issues the piece from a waterfall loop
@@ -322,13 +328,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
         constexpr int k = decltype(kc)::value;
         const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(row * G4_XROW + k * 256) * 4);
         const unsigned so = __builtin_amdgcn_readfirstlane(xb + row * xrow);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr5)(uintptr_t)ldsa, 16, pat, so, 0, 0);
+        if constexpr (G4_GLOBAL_DMA)    // global_load_lds_dwordx4 (scalar base + per-lane offset): half the issue cost of the buffer form
+            __builtin_amdgcn_global_load_lds((g4_gptr)(xbase_c + so + (unsigned)pat), (lds_void_ptr5)(uintptr_t)ldsa, 16, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr5)(uintptr_t)ldsa, 16, pat, so, 0, 0);
     };
     auto dma_g = [&](const int row, auto kc, const unsigned gb, const int pat) {
         constexpr int k = decltype(kc)::value;
         const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(G4_RAWX_F + row * G4_GROW + k * 256) * 4);
         const unsigned so = __builtin_amdgcn_readfirstlane(gb + row * grow + (k / 3) * 8 * gcs);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void_ptr5)(uintptr_t)ldsa, 16, pat, so, 0, 0);
+        if constexpr (G4_GLOBAL_DMA)
+            __builtin_amdgcn_global_load_lds((g4_gptr)(gbase_c + so + (unsigned)pat), (lds_void_ptr5)(uintptr_t)ldsa, 16, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void_ptr5)(uintptr_t)ldsa, 16, pat, so, 0, 0);
     };
     // piece schedule of an interior strip: wave w stages dL/dy row w (steps 0..5), x row w (6..8) and its share of x rows
     // 4 and 5 (9, 10): 11 / 11 / 10 / 10 pieces per wave
