@@ -37,7 +37,8 @@
 #ifndef G4_DBG
 #define G4_DBG 0   // dev builds: 1 = skip the transform, 4 = skip the contraction, 8 = stage only the first strip,
                    // 16 = do not wait for the pieces (wrong results), 32 = pieces in one burst before the contraction,
-                   // 64 = every strip stages the same pixels, 128 / 256 = degenerate per-lane patterns (issue-cost probes)
+                   // 64 = every strip stages the same pixels, 128 / 256 = degenerate per-lane patterns (issue-cost probes),
+                   // 512 = only lane 0 of every piece is active (the instruction issues, 16 bytes move)
 #endif
 #ifndef G4_STAGE_REGS
 #define G4_STAGE_REGS 0   // 1: raw tiles through registers (buffer_load_dwordx4 in steps 0..10, ds_write_b128 seven steps later) instead of LDS-DMA
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
             } else {
                 g4_contract<0>(acc, vlane, oa, ob, [&](auto stc) {
                     if constexpr (decltype(stc)::value < 11 && !(G4_DBG & 32)) {
-                        if (inner) stage_piece(stc, xb, gb, pt);
+                        if ((G4_DBG & 512) ? (inner && lane == 0) : inner) stage_piece(stc, xb, gb, pt);   // 512: one lane per piece (16 B land in LDS)
                     }
                 });
             }
