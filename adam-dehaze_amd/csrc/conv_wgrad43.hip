@@ -545,9 +545,34 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
                     }
                 });
             } else {
+                // The pieces of this wave need five scalar offsets per strip (dL/dy row w: two halves; x row w; x rows 4, 5): computed
+                // once here and pinned to SGPRs, so that a piece in the MFMA stream is s_add m0 + buffer_load and nothing else (left to
+                // hipcc the offsets lived in VGPRs under SGPR pressure: a v_add + v_readfirstlane per piece between two MFMAs)
+                unsigned sg0 = __builtin_amdgcn_readfirstlane(gb + wave * grow), sg1 = __builtin_amdgcn_readfirstlane(gb + wave * grow + 8 * gcs);
+                unsigned sx = __builtin_amdgcn_readfirstlane(xb + wave * xrow), sx4 = __builtin_amdgcn_readfirstlane(xb + 4 * xrow),
+                         sx5 = __builtin_amdgcn_readfirstlane(xb + 5 * xrow);
+                unsigned mg = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(G4_RAWX_F + wave * G4_GROW) * 4);
+                unsigned mx = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave * G4_XROW) * 4);
+                asm volatile("" : "+s"(sg0), "+s"(sg1), "+s"(sx), "+s"(sx4), "+s"(sx5), "+s"(mg), "+s"(mx));
+                auto lean = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned m0v, const int pat, const unsigned so) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr5)(uintptr_t)m0v, 16, pat, so, 0, 0);
+                };
                 g4_contract<0>(acc, vlane, oa, ob, [&](auto stc) {
-                    if constexpr (decltype(stc)::value < 11 && !(G4_DBG & 32)) {
-                        if ((G4_DBG & 512) ? (inner && lane == 0) : inner) stage_piece(stc, xb, gb, pt);   // 512: one lane per piece (16 B land in LDS)
+                    constexpr int ST = decltype(stc)::value;
+                    if constexpr (ST < 11 && !(G4_DBG & 32)) {
+                        if ((G4_DBG & 512) ? (inner && lane == 0) : inner) {   // 512: one lane per piece (16 B land in LDS)
+                            if constexpr (ST < 6) lean(gr, mg + ST * 1024, ST % 3 == 0 ? pt.g0 : (ST % 3 == 1 ? pt.g1 : pt.g2), ST < 3 ? sg0 : sg1);
+                            else if constexpr (ST < 9) lean(xr, mx + (ST - 6) * 1024, ST == 6 ? pt.x0 : (ST == 7 ? pt.x1 : pt.x2), sx);
+                            else if constexpr (ST == 9) {
+                                if (wave == 0) lean(xr, lds0 + (4 * G4_XROW + 0 * 256) * 4, pt.x0, sx4);
+                                else if (wave == 1) lean(xr, lds0 + (4 * G4_XROW + 2 * 256) * 4, pt.x2, sx4);
+                                else if (wave == 2) lean(xr, lds0 + (5 * G4_XROW + 1 * 256) * 4, pt.x1, sx5);
+                                else lean(xr, lds0 + (5 * G4_XROW + 2 * 256) * 4, pt.x2, sx5);
+                            } else {
+                                if (wave == 0) lean(xr, lds0 + (4 * G4_XROW + 1 * 256) * 4, pt.x1, sx4);
+                                else if (wave == 1) lean(xr, lds0 + (5 * G4_XROW + 0 * 256) * 4, pt.x0, sx5);
+                            }
+                        }
                     }
                 });
             }
