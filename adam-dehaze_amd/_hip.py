@@ -76,6 +76,7 @@ _SIGNATURES = {
     "adh_conv_wino43_supported": [PD],
     "adh_conv_wino43_num_blocks": [PD],
     "adh_conv_wino43_forward": [vp, PD],
+    "adh_conv_wino43_dgrad_bnred": [vp, PD, vp],
     "adh_pack_weights_wino43": [vp, vp, PL, vp],
     "adh_pack_weights_wino": [vp, vp, PL, vp],
     "adh_conv_wgrad": [vp, PD, vp, i32],
@@ -110,6 +111,7 @@ _SIGNATURES = {
     "adh_bn_bwd_num_blocks": [i64, i32],
     "adh_bn_bwd_reduce": [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp, vp],
     "adh_bn_bwd_finalize": [vp, vp, i32, i32, f64, vp, vp, vp, vp, i32, vp],
+    "adh_bn_bwd_finalize_centered": [vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, i32, vp],
     "adh_bn_partial_sums": [vp, vp, i32, i32, i32, f64, vp],
     "adh_bn_finalize_sums": [vp, vp, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp],
     "adh_bn_bwd_finalize_sums": [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp],
@@ -250,16 +252,17 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
-def call(name: str, *args, work: float = 0.0, work_exec: Optional[float] = None):
-    """Invoke a status-returning entry point on the current stream; raise on failure."""
+def call(name: str, *args, work: float = 0.0, work_exec: Optional[float] = None, family: Optional[str] = None):
+    """Invoke a status-returning entry point on the current stream; raise on failure.  `family`: the name the launch is
+    accounted under by an installed timer (an entry point that launches another entry point's kernel)."""
     timer = TIMER
-    if timer is not None and name in timer.names:
+    if timer is not None and (family or name) in timer.names:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(load(), name)(stream_ptr(), *args)
         e1.record()
-        timer.records.append((name, e0, e1, work, work if work_exec is None else work_exec))
+        timer.records.append((family or name, e0, e1, work, work if work_exec is None else work_exec))
     else:
         rc = getattr(load(), name)(stream_ptr(), *args)
     if rc != 0:

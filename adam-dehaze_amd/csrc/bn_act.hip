@@ -402,9 +402,11 @@ extern "C" int adh_bn_bwd_reduce(void* stream, const float* g_out, int g_cs, con
     return adh_check_launch();
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int pitch, int C,
                                                                double count, const float* gamma, const float* invstd,
-                                                               float* dgamma, float* dbeta, int accumulate, float* coef) {
+                                                               float* dgamma, float* dbeta, int accumulate, float* coef,
+                                                               int centered) {
+    // centered: row 1 holds sum g m (y - mean) (the fused data-gradient epilogue of conv_wino43.hip): times invstd = sum g m xhat
     // 32 channels x 32 row slices per block, four independent fp64 chains per thread (latency-bound loop)
     __shared__ double red[2][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -413,18 +415,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (c < C) {
         int b = ry;
         for (; b + 96 < nblk; b += 128) {
-            s0 += (double)partials[((size_t)b * 2 + 0) * C + c];
-            q0 += (double)partials[((size_t)b * 2 + 1) * C + c];
-            s1 += (double)partials[((size_t)(b + 32) * 2 + 0) * C + c];
-            q1 += (double)partials[((size_t)(b + 32) * 2 + 1) * C + c];
-            s2 += (double)partials[((size_t)(b + 64) * 2 + 0) * C + c];
-            q2 += (double)partials[((size_t)(b + 64) * 2 + 1) * C + c];
-            s3 += (double)partials[((size_t)(b + 96) * 2 + 0) * C + c];
-            q3 += (double)partials[((size_t)(b + 96) * 2 + 1) * C + c];
+            s0 += (double)partials[((size_t)b * 2 + 0) * pitch + c];
+            q0 += (double)partials[((size_t)b * 2 + 1) * pitch + c];
+            s1 += (double)partials[((size_t)(b + 32) * 2 + 0) * pitch + c];
+            q1 += (double)partials[((size_t)(b + 32) * 2 + 1) * pitch + c];
+            s2 += (double)partials[((size_t)(b + 64) * 2 + 0) * pitch + c];
+            q2 += (double)partials[((size_t)(b + 64) * 2 + 1) * pitch + c];
+            s3 += (double)partials[((size_t)(b + 96) * 2 + 0) * pitch + c];
+            q3 += (double)partials[((size_t)(b + 96) * 2 + 1) * pitch + c];
         }
         for (; b < nblk; b += 32) {
-            s0 += (double)partials[((size_t)b * 2 + 0) * C + c];
-            q0 += (double)partials[((size_t)b * 2 + 1) * C + c];
+            s0 += (double)partials[((size_t)b * 2 + 0) * pitch + c];
+            q0 += (double)partials[((size_t)b * 2 + 1) * pitch + c];
         }
     }
     red[0][ry][cx] = (s0 + s1) + (s2 + s3);
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
             S += red[0][r][cx];
             Q += red[1][r][cx];
         }
+        if (centered) Q *= (double)invstd[c];
         if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)Q : (float)Q;
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)S : (float)S;
         coef[0 * C + c] = (gamma ? gamma[c] : 1.f) * invstd[c];
@@ -449,7 +452,17 @@ extern "C" int adh_bn_bwd_finalize(void* stream, const float* partials, int nblk
                                    float* coef) {
     if (!partials || !invstd || !coef || nblk < 1 || C < 1 || count <= 0) return ADH_E_ARG;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(adh_ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)stream, partials,
-                       nblk, C, count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+                       nblk, C, C, count, gamma, invstd, dgamma, dbeta, accumulate, coef, 0);
+    return adh_check_launch();
+}
+
+// the same from the rows adh_conv_wino43_dgrad_bnred wrote: partials[nblk][2][pitch] = (sum g m, sum g m (y - mean))
+extern "C" int adh_bn_bwd_finalize_centered(void* stream, const float* partials, int nblk, int pitch, int C, double count,
+                                            const float* gamma, const float* invstd, float* dgamma, float* dbeta,
+                                            int accumulate, float* coef) {
+    if (!partials || !invstd || !coef || nblk < 1 || C < 1 || pitch < C || count <= 0) return ADH_E_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(adh_ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)stream, partials,
+                       nblk, pitch, C, count, gamma, invstd, dgamma, dbeta, accumulate, coef, 1);
     return adh_check_launch();
 }
 

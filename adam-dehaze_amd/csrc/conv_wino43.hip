@@ -73,6 +73,7 @@ struct Wino43Geom {
     int nchunks;
     int KQtot;
     int ncog;
+    const float* bn_mean;        // BNRED launches: the producing layer's batch mean (centres the second sum)
 };
 
 // Register class of accumulator tile (frequency FI, channel tile J): 16 tiles fit the 256 AGPRs, the other 9*NT - 16 live
@@ -211,7 +212,7 @@ __device__ __forceinline__ void w4_chunk(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], 
     }
 }
 
-template <int NT>
+template <int NT, bool BNRED = false>
 __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc d, const Wino43Geom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // V | raw | slot tables | .. | red ; M aliases V .. red
     float* const rawbase = lds + W4_VF;
@@ -439,13 +440,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const bool ragged = oy0 + 16 > d.OH || ox0 + 32 > d.OW;     // workgroup-uniform
     const float act_lo = d.act == ADH_ACT_RELU ? 0.f : -INFINITY;   // ReLU as max(v, 0), identity as max(v, -inf)
     unsigned rowpen[4], colpen[4];
-    float rowf[4], colf[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         rowpen[r] = ey0 + r < d.OH ? 0u : 0x80000000u;
         colpen[r] = ex0 + r < d.OW ? 0u : 0x80000000u;
-        rowf[r] = ey0 + r < d.OH ? 1.f : 0.f;
-        colf[r] = ex0 + r < d.OW ? 1.f : 0.f;
     }
     const unsigned o_vbase = (unsigned)((ey0 * d.OW + ex0) * o_px + (co0 + eq * 4) * 4);
     const unsigned r_vbase = (unsigned)((ey0 * d.OW + ex0) * r_px + (co0 + eq * 4) * 4);
@@ -470,6 +468,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
         if (d.scale && quad_ok) sc4 = *reinterpret_cast<const f32x4*>(d.scale + cq0);
         if (d.shift && quad_ok) sh4 = *reinterpret_cast<const f32x4*>(d.shift + cq0);
+        f32x4 mean4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BNRED) {
+            if (quad_ok) mean4 = *reinterpret_cast<const f32x4*>(g.bn_mean + cq0);
+        }
         const unsigned chanpen = quad_ok ? 0u : 0x80000000u;
         const unsigned o_vj = (o_vbase + j * 128) | chanpen, r_vj = (r_vbase + j * 128) | chanpen;
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
@@ -513,11 +515,35 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
                                     W4_A3 * d12 + W4_B3 * d34 + u[ii][5]};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
+                    if constexpr (BNRED) {
+                        // data-gradient launch that also takes the PRODUCING layer's BatchNorm-backward sums:
+                        // the output is that layer's output gradient g; `residual` is its raw convolution output y, scale /
+                        // shift its forward BN scale / shift, so m = [fma(y, scale, shift) > 0] is its ReLU mask (the forward
+                        // expression of bn_apply_kernel, bit for bit); statistics rows = sum g m, sum g m (y - mean).  g is stored as is.
+                        const f32x4 yv = rres[ii * 4 + jj];
+                        // a pixel outside the image / a padding channel quad has bit 31 of its store offset set: it does not count
+                        // (no per-pixel float masks: eight more live registers spill 80 here)
+                        const unsigned oaddr = o_vj | rowpen[2 * half + ii] | colpen[jj];
+                        const bool inside = (int)oaddr >= 0;
+                        f32x4 gm;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gm[e] = (inside && __builtin_fmaf(yv[e], sc4[e], sh4[e]) > 0.f) ? y[jj][e] : 0.f;
+                        ssum += gm;
+                        ssq += gm * adh_pksub(yv, mean4, m1);
+                        f32x4 v = y[jj];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, oaddr,
+                                                               (2 * half + ii) * o_row + jj * o_px, W_STORE_AUX);
+                        asm volatile("s_nop %1" : "+v"(v) : "n"(W4_STORE_NOPS) : "memory");
+                        continue;
+                    }
                     f32x4 v = y[jj] * sc4 + sh4;
                     if (d.stats) {
                         f32x4 vs = v;
-                        if (ragged) {   // pixels outside the image do not count (a real, workgroup-uniform branch: the asm
-                            vs = v * (rowf[2 * half + ii] * colf[jj]);   // keeps the compiler from turning it into selects)
+                        if (ragged) {   // pixels outside the image do not count (a real, workgroup-uniform branch: the asm keeps
+                            // the compiler from turning it into selects); bit 31 of the store offset marks them
+                            const bool inside = (int)(o_vj | rowpen[2 * half + ii] | colpen[jj]) >= 0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vs[e] = inside ? v[e] : 0.f;
                             asm volatile("" : "+v"(vs));
                         }
                         ssum += vs;
@@ -588,6 +614,7 @@ static int wino43_plan(const adh_conv_desc* d, Wino43Geom* g) {
     g->nregions = g->tiles_x * g->tiles_y * d->N;
     g->nchunks = d->Cin / W4_KC;
     g->KQtot = d->Cin / 4;
+    g->bn_mean = nullptr;
     return 1;
 }
 
@@ -602,27 +629,52 @@ extern "C" int adh_conv_wino43_num_blocks(const adh_conv_desc* d) {
     return g.nregions;
 }
 
-template <int NT>
+template <int NT, bool BNRED = false>
 static int launch_wino43(hipStream_t s, const adh_conv_desc* d, Wino43Geom g) {
     g.ncog = d->NcP / (32 * NT);
     const int nblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<NT, BNRED>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_wino43_kernel<NT>), dim3(nblocks), dim3(256), W4_LDS_BYTES, s, *d, g);
+    hipLaunchKernelGGL((conv_wino43_kernel<NT, BNRED>), dim3(nblocks), dim3(256), W4_LDS_BYTES, s, *d, g);
     return adh_check_launch();
+}
+
+static int wino43_check_args(const adh_conv_desc* d) {
+    if (!d->in || !d->out || !d->wp || d->NcP < d->Cout) return ADH_E_ARG;
+    if (d->out_cstride < d->Cout || (d->residual && d->res_cstride < d->Cout)) return ADH_E_ARG;
+    if (((uintptr_t)d->in & 15) || ((uintptr_t)d->wp & 15)) return ADH_E_ARG;
+    return ADH_OK;
 }
 
 extern "C" int adh_conv_wino43_forward(void* stream, const adh_conv_desc* d) {
     Wino43Geom g;
     if (!wino43_plan(d, &g)) return ADH_E_UNSUPPORTED;
-    if (!d->in || !d->out || !d->wp || d->NcP < d->Cout) return ADH_E_ARG;
-    if (d->out_cstride < d->Cout || (d->residual && d->res_cstride < d->Cout)) return ADH_E_ARG;
-    if (((uintptr_t)d->in & 15) || ((uintptr_t)d->wp & 15)) return ADH_E_ARG;
+    const int rc = wino43_check_args(d);
+    if (rc) return rc;
     const int nt = d->NcP / 32;
     hipStream_t s = (hipStream_t)stream;
     if (nt % 3 == 0) return launch_wino43<3>(s, d, g);
     if (nt % 2 == 0) return launch_wino43<2>(s, d, g);
     return launch_wino43<1>(s, d, g);
+}
+
+// Data gradient + the producing layer's BatchNorm-backward sums in one launch (see the epilogue): d describes the data-gradient
+// convolution; d->residual / res_cstride = the producer's raw convolution output y, d->scale / d->shift = its forward BN
+// scale / shift, bn_mean its batch mean, d->stats = [adh_conv_wino43_num_blocks(d)][2][NcP] rows of (sum g m, sum g m (y - mean));
+// d->act must be NONE.  adh_bn_bwd_finalize_centered turns the rows into d-gamma / d-beta / the coefficients of adh_bn_bwd_apply.
+extern "C" int adh_conv_wino43_dgrad_bnred(void* stream, const adh_conv_desc* d, const float* bn_mean) {
+    Wino43Geom g;
+    if (!wino43_plan(d, &g)) return ADH_E_UNSUPPORTED;
+    const int rc = wino43_check_args(d);
+    if (rc) return rc;
+    if (!d->residual || !d->scale || !d->shift || !d->stats || !bn_mean || d->act != ADH_ACT_NONE) return ADH_E_ARG;
+    if ((uintptr_t)bn_mean & 15) return ADH_E_ARG;
+    g.bn_mean = bn_mean;
+    const int nt = d->NcP / 32;
+    hipStream_t s = (hipStream_t)stream;
+    if (nt % 3 == 0) return launch_wino43<3, true>(s, d, g);
+    if (nt % 2 == 0) return launch_wino43<2, true>(s, d, g);
+    return launch_wino43<1, true>(s, d, g);
 }
 
 // U[f = a*6+b][k/4][n][4] = (G g G^T)[a][b];  row of G for point p: [1, p, p^2] / prod_{q != p} (p - q), for inf: [0, 0, 1]

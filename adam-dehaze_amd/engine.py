@@ -31,6 +31,9 @@ USE_WINO43 = {"0": False, "1": True}.get(os.environ.get("ADH_WINO43", "1"), os.e
 USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "1") != "0"
 W43_WGRAD_ROUNDS = int(os.environ.get("ADH_W43_WGRAD_ROUNDS", "4"))   # dev: rounds of workgroups the pixel splits may form
 USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"
+# BatchNorm-backward sums of a ConvBlock taken in the epilogue of its single consumer's data-gradient launch
+# (adh_conv_wino43_dgrad_bnred) instead of a bn_bwd_reduce pass over the same tensor (A/B switch)
+USE_BN_FUSED_REDUCE = os.environ.get("ADH_BN_FUSED_REDUCE", "1") != "0"
 # Bit-packed ReLU mask for the residual BN layers (1 bit per element written by bn_apply, read by the two backward passes
 # instead of `out`): correct and tested, but measured SLOWER on MI355X (bench, ms/step: bn_apply 8.19 -> 8.47,
 # bn_bwd_reduce 8.79 -> 9.85, bn_bwd_apply 12.78 -> 12.52; +1.1 ms in all): the byte loads double the number of
@@ -86,13 +89,15 @@ class Act:
     pixel stride (t.stride(2)) may exceed C (channel slice of a wider buffer).  `C` is the logical
     channel count; `t.shape[3]` may be larger for the small padded tensors (3->8, 1->4 channels)."""
 
-    __slots__ = ("t", "C", "grad", "needs_grad")
+    __slots__ = ("t", "C", "grad", "needs_grad", "bn_src", "bn_partial")
 
     def __init__(self, t: torch.Tensor, C: Optional[int] = None, needs_grad: bool = True):
         assert t.dim() == 4 and t.stride(3) == 1
         self.t = t
         self.C = t.shape[3] if C is None else C
         self.grad: Optional[torch.Tensor] = None
+        self.bn_src = None       # (y, {scale, shift}, mean) when this is the output of a train-mode Conv+BN+ReLU without residual
+        self.bn_partial = None   # (rows, nblk, pitch, g): that layer's BN-backward sums, taken by the launch that wrote `grad`
         self.needs_grad = needs_grad
 
     @property
@@ -204,6 +209,7 @@ class Engine:
         if act.grad is None:
             act.grad = g
         else:
+            act.bn_partial = None      # the fused sums covered the first contribution only
             H.call("adh_axpby_strided", act.grad.data_ptr(), act.grad.stride(2), g.data_ptr(), g.stride(2),
                    act.pixels, _round_up(act.C, 4), 1.0, 1.0)
 
@@ -353,8 +359,12 @@ class Engine:
         return plans
 
     def _run_gather(self, plans, src: Act, dst_t: torch.Tensor, dstC: int, w: torch.Tensor, scale=None, shift=None,
-                    residual: Optional[torch.Tensor] = None, act=H.ACT_NONE, want_stats=False):
-        """Launch every plan of one layer; returns (stats partials or None, number of stat rows)."""
+                    residual: Optional[torch.Tensor] = None, act=H.ACT_NONE, want_stats=False, bnred=None):
+        """Launch every plan of one layer; returns (stats partials or None, number of stat rows).
+        `bnred` = (y, scale_shift[2][C4], mean) of the train-mode ConvBlock that produced the tensor this data gradient is
+        the gradient of: when the layer runs as ONE F(4x4,3x3) launch the producer's BatchNorm-backward sums are taken in
+        its epilogue (adh_conv_wino43_dgrad_bnred) and returned as the stats rows; otherwise (None, 0) comes back and
+        nothing was fused."""
         descs = []
         total_blocks = 0
         for L, gm in plans:
@@ -428,6 +438,15 @@ class Engine:
                           "stem": "adh_conv_stem_num_blocks", False: "adh_conv_num_blocks"}[wino], C.byref(d))
             descs.append((d, nb, wp, wino))
             total_blocks += nb
+        if bnred is not None:
+            if len(descs) != 1 or descs[0][3] != 43 or residual is not None or scale is not None or shift is not None:
+                bnred = None
+            else:
+                y_p, ss_p, mean_p = bnred
+                d0 = descs[0][0]
+                d0.residual, d0.res_cstride = y_p.data_ptr(), y_p.stride(2)
+                d0.scale, d0.shift = ss_p[0].data_ptr(), ss_p[1].data_ptr()
+                want_stats = True
         stats = None
         if want_stats:
             NcP = descs[0][0].NcP
@@ -442,6 +461,9 @@ class Engine:
             work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
             if wino == "stem":
                 H.call("adh_conv_stem_forward", C.byref(d), work=work)
+            elif wino == 43 and bnred is not None:
+                H.call("adh_conv_wino43_dgrad_bnred", C.byref(d), bnred[2].data_ptr(), work=work, work_exec=work * 0.25,
+                       family="adh_conv_wino43_forward")
             elif wino == 43:
                 H.call("adh_conv_wino43_forward", C.byref(d), work=work, work_exec=work * 0.25)
             elif wino == 32:
@@ -646,6 +668,8 @@ class Engine:
             saved = ("plain",)
 
         o = Act(out, Cout)
+        if self.record and saved[0] == "train" and relu and residual is None and USE_BN_FUSED_REDUCE and SYNC_BN is None:
+            o.bn_src = (saved[1], saved[4], saved[2])
         if RELU_CAPTURE is not None and relu:
             RELU_CAPTURE[id(w)] = out
         if self.record:
@@ -677,11 +701,14 @@ class Engine:
             # without a residual the ReLU mask is recomputed from y (fma(y, scale, shift) > 0, the forward expression):
             # the two backward passes then read two tensors each instead of three
             mask_ss = ss.data_ptr() if (relu and residual is None) else None
-            nblk = H.value("adh_bn_bwd_num_blocks", P, C4)
-            partial = self._f(nblk, 2, C4)
-            H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
-                   y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4, mask_ss, H.ptr(mbits),
-                   work=4.0 * P * Cout * (2 if (mask_ss is not None or mbits is not None or not relu) else 3))   # g, y (+ out)
+            fused = o.bn_partial if (o.bn_partial is not None and o.bn_partial[3] is g and SYNC_BN is None) else None
+            o.bn_partial = None
+            if fused is None:
+                nblk = H.value("adh_bn_bwd_num_blocks", P, C4)
+                partial = self._f(nblk, 2, C4)
+                H.call("adh_bn_bwd_reduce", g.data_ptr(), g.stride(2), o.t.data_ptr(), o.cs, act_code, y.data_ptr(),
+                       y.stride(2), mean.data_ptr(), invstd.data_ptr(), partial.data_ptr(), P, C4, mask_ss, H.ptr(mbits),
+                       work=4.0 * P * Cout * (2 if (mask_ss is not None or mbits is not None or not relu) else 3))   # g, y (+ out)
             if C4 == Cout:
                 dgamma, dbeta = self.grad_buffer(bn.weight), self.grad_buffer(bn.bias)
             else:
@@ -696,6 +723,10 @@ class Engine:
                 SYNC_BN(glob)
                 H.call("adh_bn_bwd_finalize_sums", loc.data_ptr(), glob.data_ptr(), C4, bn.weight.data_ptr(), invstd.data_ptr(),
                        dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
+            elif fused is not None:
+                # the sums came with g: rows of (sum g m, sum g m (y - mean)) from the consumer's data-gradient epilogue
+                H.call("adh_bn_bwd_finalize_centered", fused[0].data_ptr(), fused[1], fused[2], C4, float(P), bn.weight.data_ptr(),
+                       invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
             else:
                 H.call("adh_bn_bwd_finalize", partial.data_ptr(), nblk, C4, float(P), bn.weight.data_ptr(),
                        invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr())
@@ -757,9 +788,14 @@ class Engine:
             if x.grad is None:
                 sparse = (kind == "conv" and stride == 2 and len(plans) < 4)
                 gx = self._f(x.N, x.Hh, x.Ww, _round_up(x.C, 4), zero=sparse)
-                self._run_gather(plans, gsrc, gx, x.C, w)
+                # x = ReLU(BN(conv)) of a train-mode ConvBlock and this is the first gradient to reach it: take that BN's
+                # backward sums in this launch's epilogue.  They are used only if no other gradient is added to x.grad
+                # afterwards (accum / the in-place branch below drop them; the producer checks `grad is gx`).
+                rows, nrows = self._run_gather(plans, gsrc, gx, x.C, w, bnred=x.bn_src if SYNC_BN is None else None)
                 x.grad = gx
+                x.bn_partial = (rows, nrows, _round_up(x.C, 32), gx) if rows is not None else None
             else:   # accumulate in place through the epilogue's residual input
+                x.bn_partial = None
                 self._run_gather(plans, gsrc, x.grad, x.C, w, residual=x.grad)
 
     # ------------------------------------------------------------------ attention (base_model.py:43-78)

@@ -118,6 +118,15 @@ int adh_pack_weights_wino32(void* stream, const float* src, const adh_wlayout* L
 int adh_conv_wino43_supported(const adh_conv_desc* d);
 int adh_conv_wino43_num_blocks(const adh_conv_desc* d);
 int adh_conv_wino43_forward(void* stream, const adh_conv_desc* d);
+/* The data gradient of such a layer together with the BatchNorm-backward sums of the layer that PRODUCED its input (one
+ * launch instead of the data gradient + adh_bn_bwd_reduce over the same tensor): d describes the data-gradient convolution,
+ * whose output is the producer's output gradient g; d->residual / res_cstride = the producer's raw convolution output y (not
+ * added to anything), d->scale / d->shift = the producer's forward BatchNorm scale / shift (its ReLU mask is
+ * m = [fma(y, scale, shift) > 0], as in adh_bn_apply), bn_mean = its batch mean, d->act = ADH_ACT_NONE.  g is stored unchanged;
+ * d->stats gets [adh_conv_wino43_num_blocks(d)][2][NcP] rows of (sum g m, sum g m (y - mean)) for
+ * adh_bn_bwd_finalize_centered.  For a ConvBlock whose only consumer is a 3x3 convolution -- the first half of every
+ * ResidualBlock (/root/reference models/dehazing/base_model.py:4-24,26-41). */
+int adh_conv_wino43_dgrad_bnred(void* stream, const adh_conv_desc* d, const float* bn_mean);
 int adh_pack_weights_wino43(void* stream, const float* src, const adh_wlayout* L, float* wp);
 
 /* Weight gradient of the 3x3 s1 p1 convolutions with few channels (conv_wgrad_small.hip, MFMA 16x16x4: one tile = one tap
@@ -250,6 +259,10 @@ int adh_bn_bwd_reduce(void* stream, const float* g_out, int g_cs, const float* o
 int adh_bn_bwd_finalize(void* stream, const float* partials, int nblk, int C, double count,
                         const float* gamma, const float* invstd, float* dgamma, float* dbeta,
                         int accumulate, float* coef);
+/* the same from adh_conv_wino43_dgrad_bnred's rows: partials[nblk][2][pitch] = (sum g m, sum g m (y - mean)) */
+int adh_bn_bwd_finalize_centered(void* stream, const float* partials, int nblk, int pitch, int C, double count,
+                                 const float* gamma, const float* invstd, float* dgamma, float* dbeta,
+                                 int accumulate, float* coef);
 /* pass 2: g_y = gamma*invstd*(g - mean_g - xhat*mean_gxhat); optionally g_res = g (masked).
  * training==0 (eval BN): g_y = g*scale only (coef row 0). */
 int adh_bn_bwd_apply(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,

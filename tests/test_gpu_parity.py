@@ -675,3 +675,109 @@ def test_winograd32_matches_direct_path(kind, N, Ci, Co, Hh, Ww, monkeypatch):
         assert max_abs(got[True][i], got[False][i]) < 6e-6 * scale, i
     ref_s = got[False][1]
     assert float((got[True][1] - ref_s).abs().max()) < 2e-5 * float(ref_s.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BatchNorm-backward sums in the consumer's data-gradient epilogue (adh_conv_wino43_dgrad_bnred)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,Cp,Cn,Hh,Ww", [(2, 96, 96, 40, 72), (1, 64, 32, 33, 47), (2, 48, 16, 16, 32), (1, 16, 16, 24, 40),
+                                           (1, 192, 192, 16, 64)])
+def test_fused_bn_backward_sums_match_the_reduce_pass(N, Cp, Cn, Hh, Ww):
+    """Producer: Conv(.. -> Cp) + train BN + ReLU; consumer: Conv3x3(Cp -> Cn).  The consumer's data-gradient launch with the
+    producer's sums in its epilogue must (a) write the same gradient, bit for bit, as the plain launch, and (b) give the
+    d-gamma / d-beta / coefficients of adh_bn_bwd_reduce + adh_bn_bwd_finalize, and of an fp64 evaluation (ragged regions,
+    padding channel quads, all three channel-tile widths)."""
+    dev = torch.device(DEV)
+    gen = torch.Generator().manual_seed(N * 1000 + Cp + Cn + Hh)
+    w = (torch.randn(Cn, Cp, 3, 3, generator=gen) * 0.1).to(dev).requires_grad_(True)
+    y = (torch.randn(N, Hh, Ww, Cp, generator=gen) * 1.5 + 0.7).to(dev)             # the producer's conv output (mean far from 0)
+    g_next = torch.randn(N, Hh, Ww, Cn, generator=gen).to(dev)                      # gradient wrt the consumer's conv output
+    gamma = (torch.rand(Cp, generator=gen) + 0.5).to(dev)
+    gamma[1] = -gamma[1]                                                            # a negative scale flips the mask side
+    beta = (torch.randn(Cp, generator=gen) * 0.3).to(dev)
+    P = N * Hh * Ww
+    mean = y.reshape(P, Cp).mean(0).contiguous()
+    var = y.reshape(P, Cp).var(0, unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-5)).contiguous()
+    ss = torch.stack([gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+    eng = Engine(dev, record=False)
+    plans = eng._launch_plan("conv", 3, 1, 1, w, "dgrad")
+    gsrc = Act(g_next, Cn)
+    gx_plain = torch.empty(N, Hh, Ww, Cp, device=dev)
+    gx_fused = torch.empty(N, Hh, Ww, Cp, device=dev)
+    eng._run_gather(plans, gsrc, gx_plain, Cp, w)
+    rows, nrows = eng._run_gather(plans, gsrc, gx_fused, Cp, w, bnred=(y, ss, mean))
+    assert rows is not None and nrows >= 1, "the F(4x4,3x3) data-gradient launch must take the fused form at this shape"
+    assert torch.equal(gx_plain, gx_fused)
+    pitch = rows.shape[2]
+    dg_f, db_f, coef_f = (torch.empty(Cp, device=dev), torch.empty(Cp, device=dev), torch.empty(3, Cp, device=dev))
+    H.call("adh_bn_bwd_finalize_centered", rows.data_ptr(), nrows, pitch, Cp, float(P), gamma.data_ptr(), invstd.data_ptr(),
+           dg_f.data_ptr(), db_f.data_ptr(), 0, coef_f.data_ptr())
+    nblk = H.value("adh_bn_bwd_num_blocks", P, Cp)
+    part = torch.empty(nblk, 2, Cp, device=dev)
+    H.call("adh_bn_bwd_reduce", gx_plain.data_ptr(), Cp, None, 0, H.ACT_RELU, y.data_ptr(), Cp, mean.data_ptr(), invstd.data_ptr(),
+           part.data_ptr(), P, Cp, ss.data_ptr(), None)
+    dg_r, db_r, coef_r = (torch.empty(Cp, device=dev), torch.empty(Cp, device=dev), torch.empty(3, Cp, device=dev))
+    H.call("adh_bn_bwd_finalize", part.data_ptr(), nblk, Cp, float(P), gamma.data_ptr(), invstd.data_ptr(), dg_r.data_ptr(),
+           db_r.data_ptr(), 0, coef_r.data_ptr())
+    torch.cuda.synchronize()
+    # fp64 evaluation with the forward pass's own mask expression
+    m = (torch.addcmul(ss[1], y, ss[0]) > 0).double()        # fma(y, scale, shift) > 0
+    gd = gx_plain.double() * m
+    xhat = (y.double() - mean.double()) * invstd.double()
+    db64 = gd.reshape(P, Cp).sum(0)
+    dg64 = (gd * xhat).reshape(P, Cp).sum(0)
+    for got, ref64, other in ((dg_f, dg64, dg_r), (db_f, db64, db_r)):
+        scale = float(ref64.abs().max()) + 1e-12
+        assert float((got.double() - ref64).abs().max()) < 2e-5 * scale
+        assert float((got - other).abs().max()) < 2e-5 * scale
+    assert float((coef_f - coef_r).abs().max()) < 2e-5 * (float(coef_r.abs().max()) + 1e-12)
+
+
+def test_fused_bn_backward_sums_leave_the_block_gradients_unchanged(monkeypatch):
+    """Train-mode ResidualBlock backward with and without the fused sums: same gradients; the fused entry point runs exactly
+    where it applies (conv1's BN, whose only consumer is conv2) and its sums are dropped when a second gradient reaches the
+    producer's output (here: the same block output feeding a second consumer)."""
+    import adam_dehaze_amd.engine as E
+    dev = torch.device(DEV)
+    torch.manual_seed(7)
+    block = ResidualBlock(32).to(dev).train()
+    tail = ConvBlock(32, 32, 3, 1, 1).to(dev).train()        # conv + BN + ReLU, consumed by TWO convolutions below
+    c_a = ConvBlock(32, 16, 3, 1, 1, use_bn=False, relu=False).to(dev)
+    c_b = ConvBlock(32, 16, 3, 1, 1, use_bn=False, relu=False).to(dev)
+    x = torch.randn(2, 20, 36, 32, device=dev)
+    ga, gb = torch.randn(2, 20, 36, 16, device=dev), torch.randn(2, 20, 36, 16, device=dev)
+    calls = []
+    real_call = H.call
+
+    def counting(name, *a, **k):
+        calls.append(name)
+        return real_call(name, *a, **k)
+    monkeypatch.setattr(H, "call", counting)
+
+    def run(flag):
+        monkeypatch.setattr(E, "USE_BN_FUSED_REDUCE", flag)
+        calls.clear()
+        eng = Engine(dev, record=True)
+        xa = Act(x.clone())
+        h = tail.run(eng, block.run(eng, xa, True), True)
+        oa, ob = c_a.run(eng, h, True), c_b.run(eng, h, True)
+        oa.grad, ob.grad = ga.clone(), gb.clone()
+        eng.backward()
+        torch.cuda.synchronize()
+        names = {id(p): n for mod, pre in ((block, "block."), (tail, "tail."), (c_a, "a."), (c_b, "b."))
+                 for n, p in ((pre + n_, p_) for n_, p_ in mod.named_parameters())}
+        return xa.grad.clone(), {names[k]: g.clone() for k, g in eng.param_grads.items()}, list(calls)
+    gx0, gr0, calls0 = run(False)
+    gx1, gr1, calls1 = run(True)
+    assert "adh_conv_wino43_dgrad_bnred" not in calls0
+    # fused launches: conv2's data gradient (block.conv1's BN) and the first of the two consumers of `tail` (its sums are then
+    # discarded: the second consumer accumulates into the same gradient) -> tail's and block.bn2's sums still come from the pass
+    assert calls1.count("adh_conv_wino43_dgrad_bnred") == 2
+    assert calls1.count("adh_bn_bwd_finalize_centered") == 1
+    assert calls0.count("adh_bn_bwd_reduce") - calls1.count("adh_bn_bwd_reduce") == 1      # (the bias sums use that kernel too)
+    assert rel_err(gx1, gx0) < 1e-5
+    assert gr0.keys() == gr1.keys()
+    for k in gr0:
+        scale = float(gr0[k].abs().max()) + 1e-12
+        assert float((gr1[k] - gr0[k]).abs().max()) < 2e-5 * scale, k

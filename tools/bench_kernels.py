@@ -81,6 +81,28 @@ def main():
         def wgrad():
             eng._wgrad(eng._launch_plan(kind, k, stride, pad, w, "fwd"), x, g, Cout, w)
 
+        if "bnred" in args.passes.split(",") and kind == "conv" and k == 3:
+            # DESIGN 4.13 (BatchNorm pass removal): the data-gradient launch with the producer's BN-backward sums in its
+            # epilogue (library built with -DW4_FUSE_BNRED=1) against the plain launch + the bn_bwd_reduce pass it replaces
+            yprev = torch.randn(N, Hh, Ww, Cin, device=dev)
+            sc = torch.rand(Cin, device=dev) + 0.5
+            sh = torch.randn(Cin, device=dev) * 0.1
+
+            def dgrad_fused():
+                eng._run_gather(eng._launch_plan(kind, k, stride, pad, w, "dgrad"), gsrc, gx, Cin, w, scale=sc, shift=sh,
+                                residual=yprev, want_stats=True)
+            P = N * Hh * Ww
+            mean = torch.zeros(Cin, device=dev)
+            inv = torch.ones(Cin, device=dev)
+            part = torch.empty(H.value("adh_bn_bwd_num_blocks", P, Cin), 2, Cin, device=dev)
+            mss = torch.cat([sc, sh]).contiguous()
+
+            def bn_bwd_reduce():
+                H.call("adh_bn_bwd_reduce", gx.data_ptr(), Cin, None, 0, 1, yprev.data_ptr(), Cin, mean.data_ptr(),
+                       inv.data_ptr(), part.data_ptr(), P, Cin, mss.data_ptr(), None)
+            for tag, fn in (("dgrad", dgrad), ("dgrad+bnred", dgrad_fused), ("bn_bwd_reduce", bn_bwd_reduce)):
+                print(f"{name:18s} {tag:14s} {timeit(fn, args.iters):8.3f} ms", flush=True)
+            continue
         for tag, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
             if (name == "stem7x7" and tag == "dgrad") or tag not in args.passes.split(","):
                 continue
