@@ -82,15 +82,18 @@ def main():
             eng._wgrad(eng._launch_plan(kind, k, stride, pad, w, "fwd"), x, g, Cout, w)
 
         if "bnred" in args.passes.split(",") and kind == "conv" and k == 3:
-            # DESIGN 4.13 (BatchNorm pass removal): the data-gradient launch with the producer's BN-backward sums in its
-            # epilogue (library built with -DW4_FUSE_BNRED=1) against the plain launch + the bn_bwd_reduce pass it replaces
+            # DESIGN 4.13a (BatchNorm pass removal): the data-gradient launch with the producer's BN-backward sums in its
+            # epilogue (adh_conv_wino43_dgrad_bnred) against the plain launch + the bn_bwd_reduce pass it replaces
             yprev = torch.randn(N, Hh, Ww, Cin, device=dev)
             sc = torch.rand(Cin, device=dev) + 0.5
             sh = torch.randn(Cin, device=dev) * 0.1
+            ss = torch.stack([sc, sh]).contiguous()
+            mean0 = torch.zeros(Cin, device=dev)
 
             def dgrad_fused():
-                eng._run_gather(eng._launch_plan(kind, k, stride, pad, w, "dgrad"), gsrc, gx, Cin, w, scale=sc, shift=sh,
-                                residual=yprev, want_stats=True)
+                rows, _ = eng._run_gather(eng._launch_plan(kind, k, stride, pad, w, "dgrad"), gsrc, gx, Cin, w,
+                                          bnred=(yprev, ss, mean0))
+                assert rows is not None
             P = N * Hh * Ww
             mean = torch.zeros(Cin, device=dev)
             inv = torch.ones(Cin, device=dev)
