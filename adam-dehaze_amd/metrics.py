@@ -17,6 +17,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import _hip as H
+from .detection_metrics import DetectionMetrics   # noqa: F401  (evaluation/metrics.py:126-270)
 
 CATEGORY_BY_LABEL = {0: "low_intensity", 1: "medium_intensity", 2: "high_intensity"}   # evaluate.py:160-166
 

@@ -576,14 +576,18 @@ def evaluate_joint_model(config, test_loader=None, steps: int = 2, use_lpips: bo
     return results
 
 
-def evaluate_detection(config, test_loader=None, steps: int = 1, score_threshold: float = 0.5):
+def evaluate_detection(config, test_loader=None, steps: int = 1, score_threshold: float = 0.5, annotation_file=None):
     """Detection half of evaluation/evaluate.py:179-383 on device: the detector on the hazy frames and on the routed (dehazed)
-    frames, detections with score > 0.5 (evaluate.py:327,343) converted to COCO [x, y, w, h] and counted per intensity category;
-    saved as `<evaluation.results_dir>/detection_results.json`.  COCO mAP itself (evaluation/metrics.py:126-270) needs
-    pycocotools and an annotation file, neither of which exists here: the detections are what COCOeval would be fed."""
+    frames, detections with score > 0.5 (evaluate.py:327,343) converted to COCO [x, y, w, h], counted per intensity category and
+    saved as `<evaluation.results_dir>/detection_results.json`.  With a COCO annotation file
+    (`<dataset.test_path>/annotations/instances.json`, evaluate.py:241, or `annotation_file`) the detections go through
+    `DetectionMetrics` (evaluation/metrics.py:126-270; image id = the annotation's entry for the batch's file name) and the
+    per-intensity mAP tables are written to `hazy_detection_results.json` / `dehazed_detection_results.json` and compared as in
+    evaluate.py:346-377.  Without one the reference writes an empty annotation file into the dataset directory and then fails in
+    `loadRes` on the first detection; here that case reports the detections only."""
     import json
     from .detection import create_detection_model, create_integrated_system, filter_detections
-    from .metrics import CATEGORY_BY_LABEL
+    from .metrics import CATEGORY_BY_LABEL, DetectionMetrics
     world, rank = _world_rank()
     if world > 1 and rank != 0:
         _barrier()
@@ -607,6 +611,16 @@ def evaluate_detection(config, test_loader=None, steps: int = 1, score_threshold
         _warn_synthetic(config, "evaluate_detection", rank)
         test_loader = synthetic_loader(config["dataset"]["batch_size"], config["dataset"]["img_size"], steps,
                                        seed=config["seed"] + 910000, rank=rank, device=dev)
+    if annotation_file is None:
+        annotation_file = os.path.join(str(config.get("dataset", {}).get("test_path", "")), "annotations", "instances.json")
+    dm = None
+    if os.path.exists(annotation_file):
+        dm = {"hazy": DetectionMetrics(annotation_file), "dehazed": DetectionMetrics(annotation_file)}
+        with open(annotation_file) as f:
+            id_of = {im.get("file_name"): im["id"] for im in json.load(f).get("images", [])}
+    else:
+        print(f"Annotation file not found: {annotation_file}")
+    short = {"low_intensity": "low", "medium_intensity": "medium", "high_intensity": "high"}
     counts = {"hazy": {}, "dehazed": {}}
     records = []
     with torch.no_grad():
@@ -623,12 +637,27 @@ def evaluate_detection(config, test_loader=None, steps: int = 1, score_threshold
                     for b, l, sc in zip(dets[i]["boxes_xywh"].tolist(), dets[i]["labels"].tolist(), dets[i]["scores"].tolist()):
                         records.append({"source": tag, "image_id": batch["name"][i], "category_id": int(l),
                                         "bbox": [float(v) for v in b], "score": float(sc), "intensity": cat})
+                        if dm is not None:
+                            dm[tag].add_detection_result(id_of.get(batch["name"][i], batch["name"][i]), int(l), b, sc, short[cat])
     out_dir = config.get("evaluation", {}).get("results_dir", "results")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "detection_results.json"), "w") as f:
         json.dump({"score_threshold": score_threshold, "counts": counts, "detections": records}, f, indent=1)
-    print(f"Detections with score > {score_threshold}: hazy {counts['hazy']}, dehazed {counts['dehazed']} "
-          "(COCO mAP needs pycocotools + annotations: not available in this build)")
+    print(f"Detections with score > {score_threshold}: hazy {counts['hazy']}, dehazed {counts['dehazed']}")
+    results = {"counts": counts}
+    if dm is not None:
+        for tag, title in (("hazy", "Hazy"), ("dehazed", "Dehazed")):
+            print(f"\nObject Detection on {title} Images:")
+            results[tag] = dm[tag].evaluate_by_category()
+            dm[tag].print_results(results[tag]["overall"])
+            dm[tag].save_results(results[tag], os.path.join(out_dir, f"{tag}_detection_results.json"))
+        print("\nComparison by Fog Intensity:")
+        for intensity in ("low", "medium", "high"):
+            if results["hazy"].get(intensity) and results["dehazed"].get(intensity):
+                hm, dmap = results["hazy"][intensity]["mAP"], results["dehazed"][intensity]["mAP"]
+                print(f"\n{intensity.capitalize()} Intensity:\n  Hazy mAP: {hm:.4f}\n  Dehazed mAP: {dmap:.4f}")
+                if hm != 0:
+                    print(f"  Improvement: {(dmap - hm) / hm * 100:.2f}%")
     if world > 1:
         _barrier()
-    return counts
+    return results

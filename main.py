@@ -108,7 +108,7 @@ def main():
         # evaluate.py:464-540 runs image-quality evaluation of the joint model, then object detection on dehazed frames;
         # the detector stage needs torchvision detection weights that are not in this image
         T.evaluate_joint_model(config)
-        T.evaluate_detection(config)       # detector on hazy vs dehazed frames (evaluate.py:288-344); mAP needs pycocotools + annotations
+        T.evaluate_detection(config)       # detector on hazy vs dehazed frames (evaluate.py:288-344); COCO mAP when annotations exist
     elif args.mode == "demo":
         system = T.build_joint_system(config)
         system["router"].eval()

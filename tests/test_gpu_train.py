@@ -340,3 +340,42 @@ def test_evaluate_joint_model_writes_the_reference_results_json(tmp_path):
     for v in saved.values():
         assert set(v) == {"psnr", "ssim", "lpips", "samples"}
         assert 0.0 < v["psnr"] < 100.0 and -1.0 <= v["ssim"] <= 1.0 and v["lpips"] == v["lpips"]
+
+
+def test_evaluate_detection_writes_coco_tables(tmp_path):
+    """evaluation/evaluate.py:179-383: detector on hazy and on routed frames, detections above the score threshold through
+    DetectionMetrics (COCO box mAP per fog intensity) when an annotation file exists, the three results files."""
+    import json
+    cfg = _cfg()
+    cfg["dataset"] = {"batch_size": 2, "img_size": 64, "test_path": str(tmp_path / "data")}
+    cfg["evaluation"] = {"results_dir": str(tmp_path / "results")}
+    cfg["joint_training"]["checkpoint_dir"] = str(tmp_path / "nojoint")
+    ann = tmp_path / "data" / "annotations"
+    ann.mkdir(parents=True)
+    (ann / "instances.json").write_text(json.dumps({
+        "images": [{"id": 100 + i, "file_name": f"synthetic_{i}"} for i in range(2)],
+        "annotations": [{"id": 1, "image_id": 100, "category_id": 3, "bbox": [4, 4, 40, 40], "area": 1600, "iscrowd": 0},
+                        {"id": 2, "image_id": 101, "category_id": 5, "bbox": [10, 8, 30, 50], "area": 1500, "iscrowd": 0}],
+        "categories": [{"id": i, "name": str(i)} for i in range(1, 92)]}))
+    torch.manual_seed(8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = T.evaluate_detection(cfg, steps=1, score_threshold=0.0)      # random-init detector: keep every detection
+    assert set(res) == {"counts", "hazy", "dehazed"}
+    saved = json.load(open(tmp_path / "results" / "detection_results.json"))
+    assert saved["counts"] == res["counts"] and sum(res["counts"]["hazy"].values()) == sum(1 for r in saved["detections"]
+                                                                                          if r["source"] == "hazy")
+    for tag in ("hazy", "dehazed"):
+        table = json.load(open(tmp_path / "results" / f"{tag}_detection_results.json"))
+        assert table == res[tag] and "overall" in table
+        if sum(res["counts"][tag].values()):
+            assert set(table["overall"]) == {"mAP", "mAP_50", "mAP_75", "mAP_small", "mAP_medium", "mAP_large", "AR_1", "AR_10",
+                                             "AR_100", "AR_small", "AR_medium", "AR_large"}
+            assert all(-1.0 <= v <= 1.0 for v in table["overall"].values())
+            assert set(table) - {"overall"} <= {"low", "medium", "high"}
+    # without an annotation file: detections only
+    cfg["dataset"]["test_path"] = str(tmp_path / "nodata")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res2 = T.evaluate_detection(cfg, steps=1)
+    assert set(res2) == {"counts"}
