@@ -101,14 +101,12 @@ def main():
             T.train_dehazing_model(config, level, epochs=args.epochs or 30, resume=resume_for(level))
         print("\n===== Step 3: Training Joint Model =====")
         T.train_joint_model(config, epochs=args.epochs, resume=resume_for("joint"))
-        print("\n===== Step 4: Evaluation (image quality + detections on hazy / dehazed frames) =====")
-        T.evaluate_joint_model(config)
-        T.evaluate_detection(config)
+        print("\n===== Step 4: Comprehensive Evaluation =====")
+        T.run_comprehensive_evaluation(config)
     elif args.mode == "evaluate":
-        # evaluate.py:464-540 runs image-quality evaluation of the joint model, then object detection on dehazed frames;
-        # the detector stage needs torchvision detection weights that are not in this image
-        T.evaluate_joint_model(config)
-        T.evaluate_detection(config)       # detector on hazy vs dehazed frames (evaluate.py:288-344); COCO mAP when annotations exist
+        # evaluate.py:464-540 (the reference first rewrites the checkpoint paths to a hard-coded experiment directory, main.py:143-145:
+        # here the paths of the config are used as they are)
+        T.run_comprehensive_evaluation(config)   # baseline branches, routed system, detector on hazy vs dehazed frames
     elif args.mode == "demo":
         system = T.build_joint_system(config)
         system["router"].eval()

@@ -379,3 +379,27 @@ def test_evaluate_detection_writes_coco_tables(tmp_path):
         warnings.simplefilter("ignore")
         res2 = T.evaluate_detection(cfg, steps=1)
     assert set(res2) == {"counts"}
+
+
+def test_comprehensive_evaluation_files_and_keys(tmp_path):
+    """evaluation/evaluate.py:32-92,464-540: baseline branches by ground-truth intensity, the routed system, the detector stage, and
+    comprehensive_results.json with the reference's key structure."""
+    import json
+    cfg = _cfg()
+    cfg["dataset"] = {"batch_size": 6, "img_size": 64, "test_path": str(tmp_path / "nodata")}
+    cfg["evaluation"] = {"results_dir": str(tmp_path / "results"), "visualization_dir": str(tmp_path / "vis")}
+    cfg["joint_training"]["checkpoint_dir"] = str(tmp_path / "nojoint")
+    torch.manual_seed(9)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = T.run_comprehensive_evaluation(cfg, steps=2, use_lpips=False)
+    saved = json.load(open(tmp_path / "results" / "comprehensive_results.json"))
+    assert set(saved) == {"baseline", "joint", "detection", "comparison"}
+    assert set(saved["comparison"]) == {"baseline_avg_psnr", "joint_avg_psnr", "psnr_improvement"}
+    assert {"hazy", "dehazed", "improvement_percent"} <= set(saved["detection"])
+    base = json.load(open(tmp_path / "results" / "baseline_results.json"))
+    assert base == saved["baseline"] == res["baseline"] and sum(v["samples"] for v in base.values()) == 12
+    for v in base.values():
+        assert set(v) == {"psnr", "ssim", "samples"} and 0.0 < v["psnr"] < 100.0
+    assert abs(saved["comparison"]["psnr_improvement"] - (saved["comparison"]["joint_avg_psnr"] -
+                                                          saved["comparison"]["baseline_avg_psnr"])) < 1e-9
