@@ -346,50 +346,88 @@ __device__ __forceinline__ void h2_contract(f32x16 (&acc)[24], h2_lds_vf vlane, 
 
 // x round: frequency row A of tiles 4 TH .. 4 TH + 3: row A of B^T d per patch column, then the column transform
 //   B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+// A round is split into begin (its LDS reads) and finish (arithmetic + writes) so that a wave's five rounds can be software
+// pipelined: the reads of round i + 1 are in flight while round i computes (h2_five_rounds).  Unpipelined, the transform phase
+// was LDS-latency-bound: 1.0 ms of a 4.7 ms launch for ~130 instructions per wave and strip.
 template <int A, int TH>
-__device__ __forceinline__ void h2_x_round(const float* rawx, float* V, int lane, float m1) {
-    constexpr int rA = A == 0 ? 0 : (A == 2 ? 2 : 1), rB = A == 0 ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
-    const int q16 = lane & 15, tile = 4 * TH + (lane >> 4);
-    const float* s = rawx + 3 * tile * 64 + q16 * 4;
-    f32x4 r[4];
+struct H2X {
+    f32x4 dA[4], dB[4];
+    float* dst;
+    __device__ __forceinline__ void begin(const float* rawx, const float* /*rawg*/, float* V, int lane) {
+        constexpr int rA = A == 0 ? 0 : (A == 2 ? 2 : 1), rB = A == 0 ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
+        const int q16 = lane & 15, tile = 4 * TH + (lane >> 4);
+        const float* s = rawx + 3 * tile * 64 + q16 * 4;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const f32x4 dA = *reinterpret_cast<const f32x4*>(s + rA * H2_XROW + c * 64);
-        const f32x4 dB = *reinterpret_cast<const f32x4*>(s + rB * H2_XROW + c * 64);
-        r[c] = A == 1 ? dA + dB : adh_pksub(dA, dB, m1);
+        for (int c = 0; c < 4; ++c) {
+            dA[c] = *reinterpret_cast<const f32x4*>(s + rA * H2_XROW + c * 64);
+            dB[c] = *reinterpret_cast<const f32x4*>(s + rB * H2_XROW + c * 64);
+        }
+        dst = V + (4 * A) * H2_VPLANE + tile * 160 + q16 * 4;
+        __builtin_amdgcn_sched_barrier(0);
     }
-    float* dst = V + (4 * A) * H2_VPLANE + tile * 160 + q16 * 4;
-    *reinterpret_cast<f32x4*>(dst) = adh_pksub(r[0], r[2], m1);
-    *reinterpret_cast<f32x4*>(dst + 1 * H2_VPLANE) = r[1] + r[2];
-    *reinterpret_cast<f32x4*>(dst + 2 * H2_VPLANE) = adh_pksub(r[2], r[1], m1);
-    *reinterpret_cast<f32x4*>(dst + 3 * H2_VPLANE) = adh_pksub(r[1], r[3], m1);
-    __builtin_amdgcn_sched_barrier(0);
-}
+    __device__ __forceinline__ void finish(float m1) {
+        f32x4 r[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c] = A == 1 ? dA[c] + dB[c] : adh_pksub(dA[c], dB[c], m1);
+        *reinterpret_cast<f32x4*>(dst) = adh_pksub(r[0], r[2], m1);
+        *reinterpret_cast<f32x4*>(dst + 1 * H2_VPLANE) = r[1] + r[2];
+        *reinterpret_cast<f32x4*>(dst + 2 * H2_VPLANE) = adh_pksub(r[2], r[1], m1);
+        *reinterpret_cast<f32x4*>(dst + 3 * H2_VPLANE) = adh_pksub(r[1], r[3], m1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
 // dY round: frequency row A, output-channel tile J, all 8 tiles: G' dY G'^T with G' = [[1,0,0],[1,1,1],[1,-1,1],[0,0,1]]
 // (rows / columns 1, 2 of G are these halved: the factor is applied by the reduce kernel)
 template <int A, int J>
-__device__ __forceinline__ void h2_g_round(const float* rawg, float* V, int lane, float m1) {
-    const int q8 = lane & 7, tile = lane >> 3;
-    const float* s = rawg + 3 * tile * 96 + J * 32 + q8 * 4;
-    f32x4 t[3];
+struct H2G {
+    f32x4 y[(A == 0 || A == 3) ? 1 : 3][3];
+    float* dst;
+    __device__ __forceinline__ void begin(const float* /*rawx*/, const float* rawg, float* V, int lane) {
+        const int q8 = lane & 7, tile = lane >> 3;
+        const float* s = rawg + 3 * tile * 96 + J * 32 + q8 * 4;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if constexpr (A == 0) t[c] = *reinterpret_cast<const f32x4*>(s + c * 96);
-        else if constexpr (A == 3) t[c] = *reinterpret_cast<const f32x4*>(s + 2 * H2_GROW + c * 96);
-        else {
-            const f32x4 y0 = *reinterpret_cast<const f32x4*>(s + c * 96), y1 = *reinterpret_cast<const f32x4*>(s + H2_GROW + c * 96),
-                        y2 = *reinterpret_cast<const f32x4*>(s + 2 * H2_GROW + c * 96);
-            const f32x4 e = y0 + y2;
-            t[c] = A == 1 ? e + y1 : adh_pksub(e, y1, m1);
+        for (int c = 0; c < 3; ++c) {
+            if constexpr (A == 0) y[0][c] = *reinterpret_cast<const f32x4*>(s + c * 96);
+            else if constexpr (A == 3) y[0][c] = *reinterpret_cast<const f32x4*>(s + 2 * H2_GROW + c * 96);
+            else {
+                y[0][c] = *reinterpret_cast<const f32x4*>(s + c * 96);
+                y[1][c] = *reinterpret_cast<const f32x4*>(s + H2_GROW + c * 96);
+                y[2][c] = *reinterpret_cast<const f32x4*>(s + 2 * H2_GROW + c * 96);
+            }
         }
+        dst = V + (4 * A) * H2_VPLANE + tile * 160 + 64 + J * 32 + q8 * 4;
+        __builtin_amdgcn_sched_barrier(0);
     }
-    const f32x4 e = t[0] + t[2];
-    float* dst = V + (4 * A) * H2_VPLANE + tile * 160 + 64 + J * 32 + q8 * 4;
-    *reinterpret_cast<f32x4*>(dst) = t[0];
-    *reinterpret_cast<f32x4*>(dst + 1 * H2_VPLANE) = e + t[1];
-    *reinterpret_cast<f32x4*>(dst + 2 * H2_VPLANE) = adh_pksub(e, t[1], m1);
-    *reinterpret_cast<f32x4*>(dst + 3 * H2_VPLANE) = t[2];
-    __builtin_amdgcn_sched_barrier(0);
+    __device__ __forceinline__ void finish(float m1) {
+        f32x4 t[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if constexpr (A == 0 || A == 3) t[c] = y[0][c];
+            else {
+                const f32x4 e = y[0][c] + y[2][c];
+                t[c] = A == 1 ? e + y[1][c] : adh_pksub(e, y[1][c], m1);
+            }
+        }
+        const f32x4 e = t[0] + t[2];
+        *reinterpret_cast<f32x4*>(dst) = t[0];
+        *reinterpret_cast<f32x4*>(dst + 1 * H2_VPLANE) = e + t[1];
+        *reinterpret_cast<f32x4*>(dst + 2 * H2_VPLANE) = adh_pksub(e, t[1], m1);
+        *reinterpret_cast<f32x4*>(dst + 3 * H2_VPLANE) = t[2];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+template <typename R0, typename R1, typename R2, typename R3, typename R4>
+__device__ __forceinline__ void h2_five_rounds(const float* rawx, const float* rawg, float* V, int lane, float m1) {
+    R0 r0; r0.begin(rawx, rawg, V, lane);
+    R1 r1; r1.begin(rawx, rawg, V, lane);
+    r0.finish(m1);
+    R2 r2; r2.begin(rawx, rawg, V, lane);
+    r1.finish(m1);
+    R3 r3; r3.begin(rawx, rawg, V, lane);
+    r2.finish(m1);
+    R4 r4; r4.begin(rawx, rawg, V, lane);
+    r3.finish(m1);
+    r4.finish(m1);
 }
 
 __global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_desc d, const Wg32v2Args g, float* __restrict__ slab) {
@@ -536,19 +574,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_d
 
     // ------------------------------------------------------------------ transform: 20 rounds, five per wave
     auto transform = [&]() {
-        if (wave == 0) {
-            h2_x_round<0, 0>(rawx, V, lane, m1); h2_x_round<0, 1>(rawx, V, lane, m1);
-            h2_g_round<0, 0>(rawg, V, lane, m1); h2_g_round<1, 1>(rawg, V, lane, m1); h2_g_round<2, 2>(rawg, V, lane, m1);
-        } else if (wave == 1) {
-            h2_x_round<1, 0>(rawx, V, lane, m1); h2_x_round<1, 1>(rawx, V, lane, m1);
-            h2_g_round<1, 0>(rawg, V, lane, m1); h2_g_round<2, 1>(rawg, V, lane, m1); h2_g_round<3, 2>(rawg, V, lane, m1);
-        } else if (wave == 2) {
-            h2_x_round<2, 0>(rawx, V, lane, m1); h2_x_round<2, 1>(rawx, V, lane, m1);
-            h2_g_round<2, 0>(rawg, V, lane, m1); h2_g_round<3, 1>(rawg, V, lane, m1); h2_g_round<0, 2>(rawg, V, lane, m1);
-        } else {
-            h2_x_round<3, 0>(rawx, V, lane, m1); h2_x_round<3, 1>(rawx, V, lane, m1);
-            h2_g_round<3, 0>(rawg, V, lane, m1); h2_g_round<0, 1>(rawg, V, lane, m1); h2_g_round<1, 2>(rawg, V, lane, m1);
-        }
+        if (wave == 0) h2_five_rounds<H2X<0, 0>, H2X<0, 1>, H2G<0, 0>, H2G<1, 1>, H2G<2, 2>>(rawx, rawg, V, lane, m1);
+        else if (wave == 1) h2_five_rounds<H2X<1, 0>, H2X<1, 1>, H2G<1, 0>, H2G<2, 1>, H2G<3, 2>>(rawx, rawg, V, lane, m1);
+        else if (wave == 2) h2_five_rounds<H2X<2, 0>, H2X<2, 1>, H2G<2, 0>, H2G<3, 1>, H2G<0, 2>>(rawx, rawg, V, lane, m1);
+        else h2_five_rounds<H2X<3, 0>, H2X<3, 1>, H2G<3, 0>, H2G<0, 1>, H2G<1, 2>>(rawx, rawg, V, lane, m1);
     };
 
     f32x16 acc[24];
