@@ -408,3 +408,46 @@ def test_config5_complex_eval_1024x2048_properties():
     assert torch.equal(both, again)
     assert float((both[3:4] - one).abs().max()) < 1e-6
     assert float((both - x).abs().max()) > 1e-3    # the network does something
+
+
+@pytest.mark.parametrize("Cc,hh,ww", [(96, 512, 1024), (384, 128, 256)])
+def test_fused_bn_backward_sums_full_size(Cc, hh, ww):
+    """The data-gradient launch that also takes the producing ConvBlock's BatchNorm-backward sums (adh_conv_wino43_dgrad_bnred,
+    DESIGN 4.13a) at the headline shapes (8 images; 96 channels at 512 x 1024 and 384 at 128 x 256): same gradient as the plain launch
+    bit for bit, and sums that agree with fp64 reductions over the whole 0.4-billion-element tensors done with torch on the GPU."""
+    dev = torch.device(DEV)
+    eng = _eng()
+    w = (_randn(Cc, Cc, 3, 3, seed=11) * 0.05).requires_grad_(True)
+    y = _randn(N, hh, ww, Cc, seed=12) * 1.3 + 0.4
+    g_next = _randn(N, hh, ww, Cc, seed=13)
+    gamma = torch.rand(Cc, device=dev) + 0.5
+    beta = torch.randn(Cc, device=dev) * 0.2
+    P = N * hh * ww
+    yd = y.reshape(P, Cc)
+    mean = yd.double().mean(0).float().contiguous()
+    invstd = (1.0 / torch.sqrt(yd.double().var(0, unbiased=False) + 1e-5)).float().contiguous()
+    ss = torch.stack([gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+    plans = eng._launch_plan("conv", 3, 1, 1, w, "dgrad")
+    gsrc = Act(g_next, Cc)
+    gx_plain = torch.empty(N, hh, ww, Cc, device=dev)
+    gx_fused = torch.empty(N, hh, ww, Cc, device=dev)
+    eng._run_gather(plans, gsrc, gx_plain, Cc, w)
+    rows, nrows = eng._run_gather(plans, gsrc, gx_fused, Cc, w, bnred=(y, ss, mean))
+    assert rows is not None
+    assert torch.equal(gx_plain, gx_fused)
+    del gx_fused
+    dg, db, coef = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), torch.empty(3, Cc, device=dev)
+    H.call("adh_bn_bwd_finalize_centered", rows.data_ptr(), nrows, rows.shape[2], Cc, float(P), gamma.data_ptr(), invstd.data_ptr(),
+           dg.data_ptr(), db.data_ptr(), 0, coef.data_ptr())
+    torch.cuda.synchronize()
+    db64 = torch.zeros(Cc, device=dev, dtype=torch.float64)
+    dg64 = torch.zeros(Cc, device=dev, dtype=torch.float64)
+    for n in range(N):                                          # image by image: the fp64 temporaries stay small
+        yn, gn = y[n].reshape(-1, Cc), gx_plain[n].reshape(-1, Cc)
+        m = (yn.double() * ss[0].double() + ss[1].double()) > 0     # the sign of fma(y, scale, shift): one rounding of the exact value
+        gm = torch.where(m, gn, torch.zeros((), device=dev)).double()
+        db64 += gm.sum(0)
+        dg64 += (gm * ((yn.double() - mean.double()) * invstd.double())).sum(0)
+    for got, ref in ((dg, dg64), (db, db64)):
+        assert float((got.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert float((coef[1].double() - db64 / P).abs().max()) < 2e-5 * float((db64 / P).abs().max())

@@ -722,7 +722,7 @@ def test_fused_bn_backward_sums_match_the_reduce_pass(N, Cp, Cn, Hh, Ww):
            db_r.data_ptr(), 0, coef_r.data_ptr())
     torch.cuda.synchronize()
     # fp64 evaluation with the forward pass's own mask expression
-    m = (torch.addcmul(ss[1], y, ss[0]) > 0).double()        # fma(y, scale, shift) > 0
+    m = ((y.double() * ss[0].double() + ss[1].double()) > 0).double()     # the sign of fma(y, scale, shift): one rounding of the exact value
     gd = gx_plain.double() * m
     xhat = (y.double() - mean.double()) * invstd.double()
     db64 = gd.reshape(P, Cp).sum(0)
