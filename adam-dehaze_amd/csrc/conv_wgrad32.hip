@@ -292,20 +292,35 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32_kernel(const adh_conv_des
 // 20 wave-rounds per strip (8 of x, 12 of dY), five per wave.  Conflict-free LDS images without padding: an x pixel is 256 B
 // (the 16 lanes of a ds_read_b128 group = its 16 quads), a dY pixel 384 B = 96 banks = 32 mod 64 (adjacent tiles, 3 pixels
 // apart, land in the other bank half).  Shapes: Cin % 64 == 0, Cout % 96 == 0 (ConvTranspose 384 -> 96 / 192, Conv2d k4 s2
-// 192 -> 384); everything else stays on the kernel above / the direct kernel.
+// 192 -> 384) and, with the roles of the two layouts exchanged (template parameter CI = 96: 96 input x 64 output channels,
+// 58 pieces per strip), Cin % 96 == 0, Cout % 64 == 0 (Conv2d k4 s2 96 -> 192); everything else stays on the kernel above / the
+// direct kernel.
 // =====================================================================================================================
 #ifndef H2_DBG
 #define H2_DBG 0   // dev builds (timing only): 1 = skip the transform, 4 = skip the contraction, 8 = stage only the first strip
 #endif
 #define H2_T 8
-#define H2_XROW (28 * 64)                         // floats per raw halo row: 28 pixel slots (25 used) x 64 channels
-#define H2_RAWX_F (4 * H2_XROW)                   //  7,168
-#define H2_GROW (24 * 96)                         // floats per raw dY row
-#define H2_RAWG_F (3 * H2_GROW)                   //  6,912
-#define H2_VPLANE (H2_T * 160)                    //  1,280 floats per frequency: [tile][64 ci | 96 co]
+#define H2_VPLANE (H2_T * 160)                    //  1,280 floats per frequency: [tile][CI input | CO output channels], CI + CO = 160
 #define H2_V_F (16 * H2_VPLANE)                   // 20,480
 #define H2_TAB_F (4 * 64)
-#define H2_LDS_BYTES ((H2_RAWX_F + H2_RAWG_F + H2_V_F + H2_TAB_F) * 4)   // 139,264 B
+// Channel split of the workgroup: CI = 64 input x 96 output channels (2 x 3 channel tiles) or CI = 96 x 64 (3 x 2: Conv2d k4 s2
+// 96 -> 192, whose 96 input channels do not divide by 64).  The operand with 64 channels has 256-byte pixels (DMA piece = 4
+// pixels x 16 quads, transform rounds of 4 tiles x 16 quads), the one with 96 channels 384-byte pixels (three piece patterns
+// repeating every 8 pixels, rounds of 8 tiles x 8 quads per 32-channel tile).
+template <int CI>
+struct H2L {
+    static constexpr int CO = 160 - CI;
+    static constexpr int MI = CI / 32, NJ = CO / 32;
+    static constexpr int XROW = 28 * CI;              // floats per raw halo row: 28 pixel slots (25 used)
+    static constexpr int RAWX_F = 4 * XROW;
+    static constexpr int GROW = 24 * CO;              // floats per raw dY row
+    static constexpr int RAWG_F = 3 * GROW;
+    static constexpr int NXP = CI == 64 ? 7 : 10;     // DMA pieces per raw x row
+    static constexpr int NGP = CO == 64 ? 6 : 9;      // ... per raw dY row
+    static constexpr int NSTEP = (4 * NXP + 3 * NGP + 3) / 4;   // contraction steps that carry a piece: 14 / 15 (of 16)
+    static constexpr int LDS_BYTES = (RAWX_F + RAWG_F + H2_V_F + H2_TAB_F) * 4;   // 139,264 B / 144,384 B
+};
+static_assert(H2L<64>::MI * H2L<64>::NJ == 6 && H2L<96>::MI * H2L<96>::NJ == 6, "six channel-tile pairs per frequency");
 
 struct Wg32v2Args {
     int ymin, xmin, xps;
@@ -320,49 +335,55 @@ __device__ __forceinline__ void h2_mfma(f32x16& c, float a, float b) {
 }
 typedef const volatile __attribute__((address_space(3))) float* h2_lds_vf;   // one ds_read_b32 per operand, 16-bit immediates
 // step ST = b * 4 + ks: frequency b of the wave's row, tile pair ks
-template <int ST>
-__device__ __forceinline__ void h2_load_ops(h2_lds_vf vlane, float (&a)[2], float (&b)[3]) {
+template <int CI, int ST>
+__device__ __forceinline__ void h2_load_ops(h2_lds_vf vlane, float (&a)[H2L<CI>::MI], float (&b)[H2L<CI>::NJ]) {
     h2_lds_vf p = vlane + (ST / 4) * H2_VPLANE + (ST % 4) * 320;
-    a[0] = p[0];
-    a[1] = p[32];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) b[j] = p[64 + 32 * j];
+    for (int m = 0; m < H2L<CI>::MI; ++m) a[m] = p[32 * m];
+#pragma unroll
+    for (int j = 0; j < H2L<CI>::NJ; ++j) b[j] = p[CI + 32 * j];
 }
-template <int ST, typename Hook>
-__device__ __forceinline__ void h2_contract(f32x16 (&acc)[24], h2_lds_vf vlane, float (&a)[2][2], float (&b)[2][3], Hook&& hook) {
+template <int CI, int B6, int E>
+__device__ __forceinline__ void h2_mfma_rest(f32x16 (&acc)[24], const float (&a)[H2L<CI>::MI], const float (&b)[H2L<CI>::NJ]) {
+    if constexpr (E < 6) {
+        h2_mfma<B6 + E>(acc[B6 + E], a[E / H2L<CI>::NJ], b[E % H2L<CI>::NJ]);
+        h2_mfma_rest<CI, B6, E + 1>(acc, a, b);
+    }
+}
+template <int CI, int ST, typename Hook>
+__device__ __forceinline__ void h2_contract(f32x16 (&acc)[24], h2_lds_vf vlane, float (&a)[2][H2L<CI>::MI], float (&b)[2][H2L<CI>::NJ],
+                                            Hook&& hook) {
     if constexpr (ST < 16) {
-        if constexpr (ST + 1 < 16) h2_load_ops<ST + 1>(vlane, a[(ST + 1) & 1], b[(ST + 1) & 1]);
-        constexpr int B6 = (ST / 4) * 6;
+        if constexpr (ST + 1 < 16) h2_load_ops<CI, ST + 1>(vlane, a[(ST + 1) & 1], b[(ST + 1) & 1]);
+        constexpr int B6 = (ST / 4) * 6;                          // accumulator (frequency b, ci tile m, co tile j) = b * 6 + m * NJ + j
         h2_mfma<B6 + 0>(acc[B6 + 0], a[ST & 1][0], b[ST & 1][0]);
         hook(std::integral_constant<int, ST>{});
-        h2_mfma<B6 + 1>(acc[B6 + 1], a[ST & 1][0], b[ST & 1][1]);
-        h2_mfma<B6 + 2>(acc[B6 + 2], a[ST & 1][0], b[ST & 1][2]);
-        h2_mfma<B6 + 3>(acc[B6 + 3], a[ST & 1][1], b[ST & 1][0]);
-        h2_mfma<B6 + 4>(acc[B6 + 4], a[ST & 1][1], b[ST & 1][1]);
-        h2_mfma<B6 + 5>(acc[B6 + 5], a[ST & 1][1], b[ST & 1][2]);
-        h2_contract<ST + 1>(acc, vlane, a, b, hook);
+        h2_mfma_rest<CI, B6, 1>(acc, a[ST & 1], b[ST & 1]);
+        h2_contract<CI, ST + 1>(acc, vlane, a, b, hook);
     }
 }
 
-// x round: frequency row A of tiles 4 TH .. 4 TH + 3: row A of B^T d per patch column, then the column transform
+// x round: frequency row A of B^T d B for one group R of (tile, channel quad) units
 //   B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+// 64-channel layout: R = tile half (tiles 4 R .. 4 R + 3 x 16 quads); 96-channel layout: R = 32-channel tile (8 tiles x 8 quads).
 // A round is split into begin (its LDS reads) and finish (arithmetic + writes) so that a wave's five rounds can be software
 // pipelined: the reads of round i + 1 are in flight while round i computes (h2_five_rounds).  Unpipelined, the transform phase
 // was LDS-latency-bound: 1.0 ms of a 4.7 ms launch for ~130 instructions per wave and strip.
-template <int A, int TH>
+template <int CI, int A, int R>
 struct H2X {
     f32x4 dA[4], dB[4];
     float* dst;
     __device__ __forceinline__ void begin(const float* rawx, const float* /*rawg*/, float* V, int lane) {
         constexpr int rA = A == 0 ? 0 : (A == 2 ? 2 : 1), rB = A == 0 ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
-        const int q16 = lane & 15, tile = 4 * TH + (lane >> 4);
-        const float* s = rawx + 3 * tile * 64 + q16 * 4;
+        const int tile = CI == 64 ? 4 * R + (lane >> 4) : (lane >> 3);
+        const int ch = CI == 64 ? (lane & 15) * 4 : R * 32 + (lane & 7) * 4;
+        const float* s = rawx + 3 * tile * CI + ch;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            dA[c] = *reinterpret_cast<const f32x4*>(s + rA * H2_XROW + c * 64);
-            dB[c] = *reinterpret_cast<const f32x4*>(s + rB * H2_XROW + c * 64);
+            dA[c] = *reinterpret_cast<const f32x4*>(s + rA * H2L<CI>::XROW + c * CI);
+            dB[c] = *reinterpret_cast<const f32x4*>(s + rB * H2L<CI>::XROW + c * CI);
         }
-        dst = V + (4 * A) * H2_VPLANE + tile * 160 + q16 * 4;
+        dst = V + (4 * A) * H2_VPLANE + tile * 160 + ch;
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ void finish(float m1) {
@@ -376,26 +397,28 @@ struct H2X {
         __builtin_amdgcn_sched_barrier(0);
     }
 };
-// dY round: frequency row A, output-channel tile J, all 8 tiles: G' dY G'^T with G' = [[1,0,0],[1,1,1],[1,-1,1],[0,0,1]]
-// (rows / columns 1, 2 of G are these halved: the factor is applied by the reduce kernel)
-template <int A, int J>
+// dY round: frequency row A of G' dY G'^T with G' = [[1,0,0],[1,1,1],[1,-1,1],[0,0,1]] for one group R of units (as above, by the
+// layout of the OUTPUT channels); rows / columns 1, 2 of G are these halved: the factor is applied by the reduce kernel
+template <int CI, int A, int R>
 struct H2G {
+    static constexpr int CO = H2L<CI>::CO;
     f32x4 y[(A == 0 || A == 3) ? 1 : 3][3];
     float* dst;
     __device__ __forceinline__ void begin(const float* /*rawx*/, const float* rawg, float* V, int lane) {
-        const int q8 = lane & 7, tile = lane >> 3;
-        const float* s = rawg + 3 * tile * 96 + J * 32 + q8 * 4;
+        const int tile = CO == 64 ? 4 * R + (lane >> 4) : (lane >> 3);
+        const int ch = CO == 64 ? (lane & 15) * 4 : R * 32 + (lane & 7) * 4;
+        const float* s = rawg + 3 * tile * CO + ch;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if constexpr (A == 0) y[0][c] = *reinterpret_cast<const f32x4*>(s + c * 96);
-            else if constexpr (A == 3) y[0][c] = *reinterpret_cast<const f32x4*>(s + 2 * H2_GROW + c * 96);
+            if constexpr (A == 0) y[0][c] = *reinterpret_cast<const f32x4*>(s + c * CO);
+            else if constexpr (A == 3) y[0][c] = *reinterpret_cast<const f32x4*>(s + 2 * H2L<CI>::GROW + c * CO);
             else {
-                y[0][c] = *reinterpret_cast<const f32x4*>(s + c * 96);
-                y[1][c] = *reinterpret_cast<const f32x4*>(s + H2_GROW + c * 96);
-                y[2][c] = *reinterpret_cast<const f32x4*>(s + 2 * H2_GROW + c * 96);
+                y[0][c] = *reinterpret_cast<const f32x4*>(s + c * CO);
+                y[1][c] = *reinterpret_cast<const f32x4*>(s + H2L<CI>::GROW + c * CO);
+                y[2][c] = *reinterpret_cast<const f32x4*>(s + 2 * H2L<CI>::GROW + c * CO);
             }
         }
-        dst = V + (4 * A) * H2_VPLANE + tile * 160 + 64 + J * 32 + q8 * 4;
+        dst = V + (4 * A) * H2_VPLANE + tile * 160 + CI + ch;
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ void finish(float m1) {
@@ -430,16 +453,18 @@ __device__ __forceinline__ void h2_five_rounds(const float* rawx, const float* r
     r4.finish(m1);
 }
 
-__global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_desc d, const Wg32v2Args g, float* __restrict__ slab) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // rawx | rawg | V | pattern table
+template <int CI>
+__device__ __forceinline__ void h2_workgroup(const adh_conv_desc& d, const Wg32v2Args& g, float* __restrict__ slab, float* smem) {
+    typedef H2L<CI> L;
+    constexpr int CO = L::CO, MI = L::MI, NJ = L::NJ;
     const int bid = blockIdx.x;
     const int q2 = bid >> 3;
     const int grp = q2 % g.ngroups;
     const int split = (q2 / g.ngroups) * 8 + (bid & 7);
     if (split >= g.nsplit) return;
     float* const rawx = smem;
-    float* const rawg = smem + H2_RAWX_F;
-    float* const V = rawg + H2_RAWG_F;
+    float* const rawg = smem + L::RAWX_F;
+    float* const V = rawg + L::RAWG_F;
     int* const tab = reinterpret_cast<int*>(V + H2_V_F);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -447,32 +472,34 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_d
     const int l31 = lane & 31;
     const int h = lane >> 5;
     const int cob = grp % g.ncob, cib = grp / g.ncob;
-    const int ci0 = cib * 64, co0 = cob * 96;
+    const int ci0 = cib * CI, co0 = cob * CO;
 
     const int xcs = d.in_cstride * 4 * g.xps, gcs = d.out_cstride * 4 * d.out_sx;
     const int xrs = d.IW * d.in_cstride * 4 * g.xps, grs = d.OW * d.out_cstride * 4 * d.out_sy;
     const float* xbase = d.in + ((int64_t)g.ymin * d.IW + g.xmin) * d.in_cstride + ci0;
     const float* gbase = d.out + ((int64_t)d.out_oy * d.OW + d.out_ox) * d.out_cstride + co0;
     const int64_t ximg = (int64_t)d.IH * d.IW * d.in_cstride, gimg = (int64_t)d.OH * d.OW * d.out_cstride;
-    // per-lane global offsets of the pieces: x piece = 4 pixels x 16 quads; dY pieces k, k + 3 are 8 pixels apart
+    // per-lane global offsets of the pieces.  64-channel operand: piece = 4 pixels x 16 quads, one pattern.  96-channel operand: a
+    // piece is 1 KB of 384-byte pixels, three patterns; pieces k, k + 3 are 8 pixels apart
+    const int cs64 = CI == 64 ? xcs : gcs, cs96 = CI == 64 ? gcs : xcs;
     if (tid < 64) {
-        tab[tid] = (tid >> 4) * xcs + (tid & 15) * 16;
+        tab[tid] = (tid >> 4) * cs64 + (tid & 15) * 16;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int b = 1024 * k + 16 * tid;
-            tab[(1 + k) * 64 + tid] = (b / 384) * gcs + (b % 384);
+            tab[(1 + k) * 64 + tid] = (b / 384) * cs96 + (b % 384);
         }
     }
     __syncthreads();
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_ptr_g32)smem;
     const float m1 = adh_opaque(-1.f);
 
-    struct Pat { int x, g0, g1, g2; };
+    struct Pat { int p64, p96[3]; };
     auto load_patterns = [&]() {
         typedef const volatile __attribute__((address_space(3))) int* lds_vi;
         lds_vi t = (lds_vi)(tab + lane);
         Pat p;
-        p.x = t[0]; p.g0 = t[64]; p.g1 = t[128]; p.g2 = t[192];
+        p.p64 = t[0]; p.p96[0] = t[64]; p.p96[1] = t[128]; p.p96[2] = t[192];
         return p;
     };
     struct Geom { __amdgpu_buffer_rsrc_t xr, gr; int vy0, vx0, iy0, ix0; unsigned xb, gb; bool interior; };
@@ -495,34 +522,46 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_d
                      t.vy0 + 3 <= d.VH && t.vx0 + 24 <= d.VW;
         return t;
     };
+    // piece pc of raw x row `row` / piece k of raw dY row `row` (first pixel of the piece: 4 pc resp. 8 (pc / 3) + pattern)
     auto dma_x = [&](const Geom& t, const int row, const int pc, const int pat) {
-        const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(row * H2_XROW + pc * 256) * 4);
-        const unsigned so = __builtin_amdgcn_readfirstlane(t.xb + row * xrs + pc * 4 * xcs);
+        const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(row * L::XROW + pc * 256) * 4);
+        const unsigned so = __builtin_amdgcn_readfirstlane(t.xb + row * xrs + (CI == 64 ? pc * 4 : (pc / 3) * 8) * xcs);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(t.xr, (lds_void_ptr_g32)(uintptr_t)ldsa, 16, pat, so, 0, 0);
     };
     auto dma_g = [&](const Geom& t, const int row, const int k, const int pat) {
-        const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(H2_RAWX_F + row * H2_GROW + k * 256) * 4);
-        const unsigned so = __builtin_amdgcn_readfirstlane(t.gb + row * grs + (k / 3) * 8 * gcs);
+        const unsigned ldsa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(L::RAWX_F + row * L::GROW + k * 256) * 4);
+        const unsigned so = __builtin_amdgcn_readfirstlane(t.gb + row * grs + (CO == 64 ? k * 4 : (k / 3) * 8) * gcs);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(t.gr, (lds_void_ptr_g32)(uintptr_t)ldsa, 16, pat, so, 0, 0);
     };
-    // piece ST (0..13) of this wave: waves 0..2: dY row w pieces 0..5, x row w pieces 0..6, then x row 3 piece 5 / 6 (waves 0 / 1);
-    // wave 3: dY pieces 6..8 of rows 0..2, then x row 3 pieces 0..4.  dY pieces at steps 0..8 use pattern ST % 3 on every wave.
+    // piece of contraction step ST on this wave; the pattern of a 96-channel piece is ST % 3 on every wave (compile time).
+    // CI = 64: waves 0..2: dY row w pieces 0..5, x row w pieces 0..6, then x row 3 piece 5 / 6 (waves 0 / 1); wave 3: dY pieces 6..8 of
+    //          rows 0..2, then x row 3 pieces 0..4 (steps 0..13).
+    // CI = 96: wave w: x row w pieces 0..9 (steps 0..9), then the 18 dY pieces dealt e = w + 4 j (steps 10 + j, j = 0..4).
     auto stage_piece = [&](auto stc, const Geom& t, const Pat& p) {
         constexpr int ST = decltype(stc)::value;
-        const int gpat = ST % 3 == 0 ? p.g0 : (ST % 3 == 1 ? p.g1 : p.g2);
-        if constexpr (ST < 6) {
-            if (wave < 3) dma_g(t, wave, ST, gpat);
-            else dma_g(t, ST / 3, 6 + ST % 3, gpat);
-        } else if constexpr (ST < 9) {
-            if (wave < 3) dma_x(t, wave, ST - 6, p.x);
-            else dma_g(t, 2, 6 + ST % 3, gpat);
-        } else if constexpr (ST < 13) {
-            if (wave < 3) dma_x(t, wave, ST - 6, p.x);
-            else dma_x(t, 3, ST - 9, p.x);
-        } else if constexpr (ST == 13) {
-            if (wave == 0) dma_x(t, 3, 5, p.x);
-            else if (wave == 1) dma_x(t, 3, 6, p.x);
-            else if (wave == 3) dma_x(t, 3, 4, p.x);
+        const int p96 = p.p96[ST % 3];
+        if constexpr (CI == 64) {
+            if constexpr (ST < 6) {
+                if (wave < 3) dma_g(t, wave, ST, p96);
+                else dma_g(t, ST / 3, 6 + ST % 3, p96);
+            } else if constexpr (ST < 9) {
+                if (wave < 3) dma_x(t, wave, ST - 6, p.p64);
+                else dma_g(t, 2, 6 + ST % 3, p96);
+            } else if constexpr (ST < 13) {
+                if (wave < 3) dma_x(t, wave, ST - 6, p.p64);
+                else dma_x(t, 3, ST - 9, p.p64);
+            } else if constexpr (ST == 13) {
+                if (wave == 0) dma_x(t, 3, 5, p.p64);
+                else if (wave == 1) dma_x(t, 3, 6, p.p64);
+                else if (wave == 3) dma_x(t, 3, 4, p.p64);
+            }
+        } else {
+            if constexpr (ST < 10) {
+                dma_x(t, wave, ST, p96);
+            } else if constexpr (ST < 15) {
+                const int e = wave + 4 * (ST - 10);
+                if (e < 18) dma_g(t, e / 6, e % 6, p.p64);
+            }
         }
     };
     auto stage_interior = [&](const Geom& t) {
@@ -541,6 +580,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_d
         stage_piece(std::integral_constant<int, 11>{}, t, p);
         stage_piece(std::integral_constant<int, 12>{}, t, p);
         stage_piece(std::integral_constant<int, 13>{}, t, p);
+        stage_piece(std::integral_constant<int, 14>{}, t, p);
     };
     // border / ragged strip: zero both raw images, then load only what lies inside the image / the class grid
     auto stage_border = [&](const int sb) {
@@ -549,35 +589,43 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_d
         asm volatile("" : "+v"(ln), "+v"(td));        // keeps LICM from hoisting this rare path's lane predicates out of the loop
         const Pat p = load_patterns();
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int i = td; i < (H2_RAWX_F + H2_RAWG_F) / 4; i += 256) *reinterpret_cast<f32x4*>(smem + i * 4) = z;
+        for (int i = td; i < (L::RAWX_F + L::RAWG_F) / 4; i += 256) *reinterpret_cast<f32x4*>(smem + i * 4) = z;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         {
-            const int row = wave;                         // x row w, 7 pieces
+            const int row = wave;                         // x row w
             const int iy = t.iy0 + row * g.xps;
 #pragma unroll 1
-            for (int pc = 0; pc < 7; ++pc) {
-                const int c = pc * 4 + (ln >> 4);
+            for (int pc = 0; pc < L::NXP; ++pc) {
+                const int c = CI == 64 ? pc * 4 + (ln >> 4) : (1024 * (pc % 3) + 16 * ln) / 384 + 8 * (pc / 3);
                 const int ix = t.ix0 + c * g.xps;
-                if (c < 25 && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) dma_x(t, row, pc, p.x);
+                if (c < 25 && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
+                    dma_x(t, row, pc, CI == 64 ? p.p64 : (pc % 3 == 0 ? p.p96[0] : (pc % 3 == 1 ? p.p96[1] : p.p96[2])));
             }
         }
-        if (wave < 3) {                                   // dY row w, 9 pieces
+        if (wave < 3) {                                   // dY row w
             const int row = wave;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int px = (1024 * (k % 3) + 16 * ln) / 384 + 8 * (k / 3);
-                if (t.vy0 + row < d.VH && t.vx0 + px < d.VW) dma_g(t, row, k, k % 3 == 0 ? p.g0 : (k % 3 == 1 ? p.g1 : p.g2));
+            for (int k = 0; k < L::NGP; ++k) {
+                const int px = CO == 64 ? k * 4 + (ln >> 4) : (1024 * (k % 3) + 16 * ln) / 384 + 8 * (k / 3);
+                if (t.vy0 + row < d.VH && t.vx0 + px < d.VW) dma_g(t, row, k, CO == 64 ? p.p64 : p.p96[k % 3]);
             }
         }
     };
 
     // ------------------------------------------------------------------ transform: 20 rounds, five per wave
     auto transform = [&]() {
-        if (wave == 0) h2_five_rounds<H2X<0, 0>, H2X<0, 1>, H2G<0, 0>, H2G<1, 1>, H2G<2, 2>>(rawx, rawg, V, lane, m1);
-        else if (wave == 1) h2_five_rounds<H2X<1, 0>, H2X<1, 1>, H2G<1, 0>, H2G<2, 1>, H2G<3, 2>>(rawx, rawg, V, lane, m1);
-        else if (wave == 2) h2_five_rounds<H2X<2, 0>, H2X<2, 1>, H2G<2, 0>, H2G<3, 1>, H2G<0, 2>>(rawx, rawg, V, lane, m1);
-        else h2_five_rounds<H2X<3, 0>, H2X<3, 1>, H2G<3, 0>, H2G<0, 1>, H2G<1, 2>>(rawx, rawg, V, lane, m1);
+        if constexpr (CI == 64) {
+            if (wave == 0) h2_five_rounds<H2X<64, 0, 0>, H2X<64, 0, 1>, H2G<64, 0, 0>, H2G<64, 1, 1>, H2G<64, 2, 2>>(rawx, rawg, V, lane, m1);
+            else if (wave == 1) h2_five_rounds<H2X<64, 1, 0>, H2X<64, 1, 1>, H2G<64, 1, 0>, H2G<64, 2, 1>, H2G<64, 3, 2>>(rawx, rawg, V, lane, m1);
+            else if (wave == 2) h2_five_rounds<H2X<64, 2, 0>, H2X<64, 2, 1>, H2G<64, 2, 0>, H2G<64, 3, 1>, H2G<64, 0, 2>>(rawx, rawg, V, lane, m1);
+            else h2_five_rounds<H2X<64, 3, 0>, H2X<64, 3, 1>, H2G<64, 3, 0>, H2G<64, 0, 1>, H2G<64, 1, 2>>(rawx, rawg, V, lane, m1);
+        } else {   // three x rounds (one per 32-channel tile) of the wave's own frequency row, one heavy + one light dY round
+            if (wave == 0) h2_five_rounds<H2X<96, 0, 0>, H2X<96, 0, 1>, H2X<96, 0, 2>, H2G<96, 1, 0>, H2G<96, 0, 0>>(rawx, rawg, V, lane, m1);
+            else if (wave == 1) h2_five_rounds<H2X<96, 1, 0>, H2X<96, 1, 1>, H2X<96, 1, 2>, H2G<96, 1, 1>, H2G<96, 0, 1>>(rawx, rawg, V, lane, m1);
+            else if (wave == 2) h2_five_rounds<H2X<96, 2, 0>, H2X<96, 2, 1>, H2X<96, 2, 2>, H2G<96, 2, 0>, H2G<96, 3, 0>>(rawx, rawg, V, lane, m1);
+            else h2_five_rounds<H2X<96, 3, 0>, H2X<96, 3, 1>, H2X<96, 3, 2>, H2G<96, 2, 1>, H2G<96, 3, 1>>(rawx, rawg, V, lane, m1);
+        }
     };
 
     f32x16 acc[24];
@@ -607,11 +655,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_d
         Geom tn = strip_geom(more ? sn : s);
         const bool inner = more && tn.interior;
         if (!(H2_DBG & 4)) {
-            float oa[2][2], ob[2][3];
-            h2_load_ops<0>(vlane, oa[0], ob[0]);
+            float oa[2][MI], ob[2][NJ];
+            h2_load_ops<CI, 0>(vlane, oa[0], ob[0]);
             const Pat pt = load_patterns();
-            h2_contract<0>(acc, vlane, oa, ob, [&](auto stc) {
-                if constexpr (decltype(stc)::value < 14) {
+            h2_contract<CI, 0>(acc, vlane, oa, ob, [&](auto stc) {
+                if constexpr (decltype(stc)::value < L::NSTEP) {
                     if (inner) stage_piece(stc, tn, pt);
                 }
             });
@@ -628,16 +676,27 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_d
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MI; ++m)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 float* base = sbase + ((size_t)b * KP + ci0 + 32 * m) * d.NcP + co0 + 32 * j + l31;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    base[(size_t)i * d.NcP] = acc[(b * 2 + m) * 3 + j][r];
+                    base[(size_t)i * d.NcP] = acc[(b * MI + m) * NJ + j][r];
                 }
             }
+}
+
+// (two plain kernels instead of one kernel template: hipcc's host pass rejects the template-id of this kernel -- "substitution
+// failure" without a reason -- once the body instantiates its generic lambdas)
+__global__ __launch_bounds__(256, 1) void conv_wgrad32v2_kernel(const adh_conv_desc d, const Wg32v2Args g, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // rawx | rawg | V | pattern table
+    h2_workgroup<64>(d, g, slab, smem);
+}
+__global__ __launch_bounds__(256, 1) void conv_wgrad32v2c96_kernel(const adh_conv_desc d, const Wg32v2Args g, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    h2_workgroup<96>(d, g, slab, smem);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -647,7 +706,7 @@ struct Wg32Class {
 };                                   // rev: taps walk backwards, halo offset (hy, hx) belongs to tap (1 - hy, 1 - hx)
 struct Wg32Plan {
     int ncls, TN;
-    int v2;                          // conv_wgrad32v2_kernel (Cin % 64 == 0, Cout % 96 == 0)
+    int v2;                          // conv_wgrad32v2_kernel<CI>: 64 (Cin % 64 == 0, Cout % 96 == 0), 96 (Cin % 96 == 0, Cout % 64 == 0), 0 = no
     int S, SX, TY, ncob;             // its strips (3 x 24 class-grid pixels) and output-channel groups
     Wg32Args base;
     Wg32Class cls[4];
@@ -665,7 +724,11 @@ static int wgrad32_plan(const adh_conv_desc* d, int nsplit, Wg32Plan* p) {
     // 384 -> 96 10.25 -> 8.4 ms, but Conv2d k4 s2 96 -> 192 5.2 -> 6.2 ms.  The four-class (k4 s2) form therefore stays on
     // the direct kernel unless forced.
     static const bool v2_enabled = !(getenv("ADH_WGRAD32_V2") && getenv("ADH_WGRAD32_V2")[0] == '0');   // A/B switch
-    p->v2 = v2_enabled && d->Cin % 64 == 0 && d->NcP % 96 == 0 && d->Cout == d->NcP;
+    p->v2 = 0;
+    if (v2_enabled && d->Cout == d->NcP) {
+        if (d->Cin % 64 == 0 && d->NcP % 96 == 0) p->v2 = 64;
+        else if (d->Cin % 96 == 0 && d->NcP % 64 == 0) p->v2 = 96;
+    }
     if (mode < 2 && d->KH == 4 && !p->v2) return 0;
     if (d->Cin % 32 != 0 || d->Cout % 4 != 0 || d->NcP != adh_round_up(d->Cout, 32)) return 0;
     if (d->in_cstride % 4 != 0 || d->out_cstride % 4 != 0) return 0;
@@ -687,8 +750,8 @@ static int wgrad32_plan(const adh_conv_desc* d, int nsplit, Wg32Plan* p) {
         p->SX = adh_ceil_div(d->VW, 3 * H2_T);
         p->TY = b.tiles_y;
         p->S = p->SX * p->TY * d->N;
-        p->ncob = d->NcP / 96;
-        b.ngroups = (d->Cin / 64) * p->ncob;
+        p->ncob = d->NcP / (160 - p->v2);
+        b.ngroups = (d->Cin / p->v2) * p->ncob;
         b.ntiles = p->S;
     }
     const int s = d->in_sy, ds = d->dstep_y;
@@ -749,12 +812,15 @@ extern "C" int adh_conv_wgrad_wino32(void* stream, const adh_conv_desc* d, float
     if (p.v2) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad32v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad32v2c96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
         for (int c = 0; c < p.ncls; ++c) {
             Wg32v2Args a;
             a.ymin = p.cls[c].ymin; a.xmin = p.cls[c].xmin; a.xps = p.cls[c].xps;
             a.S = p.S; a.SX = p.SX; a.TY = p.TY; a.nsplit = nsplit; a.ngroups = p.base.ngroups; a.ncob = p.ncob;
             a.cls = c; a.ncls = p.ncls;
-            hipLaunchKernelGGL(conv_wgrad32v2_kernel, dim3(nblocks), dim3(256), H2_LDS_BYTES, s, *d, a, slab);
+            if (p.v2 == 64) hipLaunchKernelGGL(conv_wgrad32v2_kernel, dim3(nblocks), dim3(256), H2L<64>::LDS_BYTES, s, *d, a, slab);
+            else hipLaunchKernelGGL(conv_wgrad32v2c96_kernel, dim3(nblocks), dim3(256), H2L<96>::LDS_BYTES, s, *d, a, slab);
             const int rc = adh_check_launch();
             if (rc) return rc;
         }

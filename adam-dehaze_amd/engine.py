@@ -134,19 +134,32 @@ class BNState:
         self.num_batches_tracked = num_batches_tracked
 
 
-def _rows_nsplit(groups: int, ntiles: int, cus: int = 256, max_rounds: int = 4) -> int:
-    """Pixel splits for the row-split weight-gradient kernel: one workgroup is resident per CU, so pick the
-    smallest nsplit (up to `max_rounds` rounds) whose groups*nsplit workgroups fill whole rounds of `cus` best."""
-    best, best_eff = 1, 0.0
-    for ns in range(1, max(1, min(ntiles, max_rounds * cus // max(1, groups) + 1)) + 1):
-        total = groups * ns
-        rounds = -(-total // cus)
-        eff = total / (rounds * cus)
-        # tiles per split must also divide evenly enough
-        per = -(-ntiles // ns)
-        eff *= ntiles / (per * ns)
-        if eff > best_eff + 1e-3:
-            best, best_eff = ns, eff
+_SLAB_BUDGET = 1 << 30      # bytes of split-accumulation slab a weight-gradient launch may write (and its reduce kernel read)
+
+
+def _rows_nsplit(groups: int, ntiles: int, cus: int = 256, max_rounds: int = 4, max_splits: Optional[int] = None,
+                 slab_bytes: int = 0, tile_us: float = 5.0, launches: int = 1) -> int:
+    """Pixel splits for the split-accumulating weight-gradient kernels.  One workgroup is resident per CU and the hardware deals
+    workgroups to the 8 XCDs round-robin (block b runs on XCD b % 8, 32 CUs each); every such kernel maps block b to
+    (group, split) = ((b >> 3) % groups, (b >> 3) / groups * 8 + (b & 7)), i.e. XCD x gets the splits = x mod 8 of every
+    group.  A launch therefore takes rounds = ceil(groups * ceil(nsplit / 8) / 32) workgroup times of ceil(ntiles / nsplit)
+    tiles each -- NOT ceil(groups * nsplit / 256): groups = 3, nsplit = 85 is 255 workgroups but 33 on each of XCDs 0-4, two
+    rounds (measured: Conv2d k4 s2 96 -> 192 weight gradient 5.92 ms with 85 splits, 3.69 with 80).  Every split also writes
+    `slab_bytes` of partial sums that the reduce kernel reads back (80 -> 160 splits on the same layer: 3.69 -> 3.78 ms although
+    the rounds * tiles product is the same).  Returns the nsplit (up to `max_rounds` rounds, at most `max_splits`) that
+    minimises  launches * rounds * tiles per split * tile_us  +  nsplit * 2 * slab_bytes / (4 TB/s),  smallest on ties."""
+    if os.environ.get("ADH_NSPLIT"):          # development: force the split count
+        return max(1, min(ntiles, int(os.environ["ADH_NSPLIT"])))
+    per_xcd = max(1, cus // 8)
+    limit = max(1, min(ntiles, max_rounds * cus // max(1, groups) + 1))
+    if max_splits is not None:
+        limit = max(1, min(limit, max_splits))
+    best, best_cost = 1, None
+    for ns in range(1, limit + 1):
+        rounds = -(-(groups * (-(-ns // 8))) // per_xcd)
+        cost = launches * rounds * (-(-ntiles // ns)) * tile_us + ns * 2.0 * slab_bytes / 4.0e6
+        if best_cost is None or cost < best_cost * (1.0 - 5e-3):
+            best, best_cost = ns, cost
     return best
 
 
@@ -524,7 +537,8 @@ class Engine:
             if w43_groups:
                 # 3x3 stride-1, Cin % 32 == 0, Cout % 96 == 0: accumulate in the F(4x4,3x3) domain (36 frequency slabs)
                 nstrips = H.value("adh_conv_wgrad_wino43_strips", C.byref(d))
-                nsplit = _rows_nsplit(w43_groups, nstrips, max_rounds=W43_WGRAD_ROUNDS)
+                nsplit = _rows_nsplit(w43_groups, nstrips, max_rounds=W43_WGRAD_ROUNDS, slab_bytes=36 * KP * NcP * 4,
+                                      max_splits=max(1, _SLAB_BUDGET // (36 * KP * NcP * 4)), tile_us=3.6)
                 while nsplit * 36 * KP * NcP * 4 > (1 << 30) and nsplit > 1:
                     nsplit //= 2
                 slab = self._f(nsplit * 36 * KP * NcP)
@@ -535,7 +549,8 @@ class Engine:
             wino_groups = H.value("adh_conv_wgrad_wino_groups", C.byref(d)) if USE_WINOGRAD else 0
             if wino_groups:
                 # 3x3 stride-1: accumulate in the Winograd domain (16 frequency slabs), G^T(.)G in the reduce
-                nsplit = _rows_nsplit(wino_groups, ntiles_est)
+                nsplit = _rows_nsplit(wino_groups, ntiles_est, slab_bytes=16 * KP * NcP * 4,
+                                      max_splits=max(1, _SLAB_BUDGET // (16 * KP * NcP * 4)), tile_us=8.6)
                 while nsplit * 16 * KP * NcP * 4 > (1 << 30) and nsplit > 1:
                     nsplit //= 2
                 slab = self._f(nsplit * 16 * KP * NcP)
@@ -548,7 +563,9 @@ class Engine:
                 # the 2x2-tap forms (k4 s2 / transposed layers): accumulate in the F(3x3,2x2) domain, 16 frequency slabs per
                 # class, A^T(.)A in the reduce
                 ncls = H.value("adh_conv_wgrad_wino32_classes", C.byref(d))
-                nsplit = _rows_nsplit(w32_groups, H.value("adh_conv_wgrad_wino32_tiles", C.byref(d)))
+                nsplit = _rows_nsplit(w32_groups, H.value("adh_conv_wgrad_wino32_tiles", C.byref(d)), launches=ncls,
+                                      slab_bytes=ncls * 16 * KP * NcP * 4, tile_us=5.0,
+                                      max_splits=max(1, _SLAB_BUDGET // (ncls * 16 * KP * NcP * 4)))
                 while nsplit * ncls * 16 * KP * NcP * 4 > (1 << 30) and nsplit > 1:
                     nsplit //= 2
                 slab = self._f(nsplit * ncls * 16 * KP * NcP)

@@ -441,6 +441,9 @@ def test_winograd_weight_gradient_matches_direct(N, Ci, Co, Hh, Ww, algo, monkey
     ("conv", 2, 192, 96, 24, 100),     # conv_wgrad32v2_kernel (Cin % 64 == 0, Cout % 96 == 0): four classes, ragged strips
     ("convT", 2, 128, 192, 11, 37),    # v2, two output-channel groups, ragged in both directions
     ("convT", 1, 64, 96, 30, 96),      # v2, interior strips (class grid 30 x 96: 4 strips per row)
+    ("conv", 2, 96, 192, 26, 100),     # conv_wgrad32v2_kernel<96> (Cin % 96 == 0, Cout % 64 == 0): the headline Conv2d k4 s2 96 -> 192, ragged
+    ("convT", 1, 96, 128, 11, 37),     # v2<96>, transposed, two output-channel groups, ragged in both directions
+    ("conv", 1, 192, 64, 48, 192),     # v2<96>, two input-channel groups, interior strips (class grid 24 x 96)
 ])
 def test_wino32_weight_gradient_matches_direct(kind, N, Ci, Co, Hh, Ww, monkeypatch):
     """F(3x3,2x2)-domain weight gradient of the 2x2-tap forms (conv_wgrad32_kernel + adh_wgrad_reduce_wino32) against the

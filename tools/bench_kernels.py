@@ -49,6 +49,8 @@ def main():
         ("down96to192", 96, 192, 512, 1024, "conv", 4, 2, 1),
         ("up384to96", 384, 96, 256, 512, "convT", 4, 2, 1),
         ("down192to384", 192, 384, 256, 512, "conv", 4, 2, 1),
+        ("probe_down128to192", 128, 192, 512, 1024, "conv", 4, 2, 1),     # (not a model layer: the 64 x 96 split at the full-res geometry)
+        ("probe_down96to128", 96, 128, 512, 1024, "conv", 4, 2, 1),       # (the 96 x 64 split with two output groups)
         ("up384to192", 384, 192, 128, 256, "convT", 4, 2, 1),
         ("stem7x7", 8, 96, 512, 1024, "conv", 7, 1, 3),
     ]
