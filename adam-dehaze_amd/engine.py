@@ -34,6 +34,18 @@ USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"
 # BatchNorm-backward sums of a ConvBlock taken in the epilogue of its single consumer's data-gradient launch
 # (adh_conv_wino43_dgrad_bnred) instead of a bn_bwd_reduce pass over the same tensor (A/B switch)
 USE_BN_FUSED_REDUCE = os.environ.get("ADH_BN_FUSED_REDUCE", "1") != "0"
+# the output-parity class launches of one transposed layer on separate streams (their partial last rounds overlap): measured
+# -0.2 .. -0.4 ms per layer in isolation, +1.5 ms on the whole step -- opt-in
+CLASS_STREAMS = os.environ.get("ADH_CLASS_STREAMS", "0") != "0"
+_SIDE_STREAMS: Dict[tuple, list] = {}
+
+
+def _side_streams(device: torch.device, n: int):
+    key = (device.type, device.index)
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
 # Bit-packed ReLU mask for the residual BN layers (1 bit per element written by bn_apply, read by the two backward passes
 # instead of `out`): correct and tested, but measured SLOWER on MI355X (bench, ms/step: bn_apply 8.19 -> 8.47,
 # bn_bwd_reduce 8.79 -> 9.85, bn_bwd_apply 12.78 -> 12.52; +1.1 ms in all): the byte loads double the number of
@@ -467,9 +479,27 @@ class Engine:
         row = 0
         row_i = 0
         flops_kn = [L.K * L.Nc for L, _ in plans]
+        # The output-parity classes of a transposed form are independent launches whose grids are not multiples of the CU count
+        # (e.g. 1056 workgroups = 4.125 rounds of one workgroup per CU: the last round runs on 1/8 of the chip).  On separate
+        # streams the next class fills the CUs the previous one's tail leaves idle.
+        fork = None
+        if CLASS_STREAMS and len(descs) > 1 and all(w == 32 for _, _, _, w in descs):
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side = _side_streams(self.device, min(4, len(descs)))
         for d, nb, _wp, wino in descs:
             if stats is not None:
                 d.stats = stats.data_ptr() + row * 2 * d.NcP * 4
+            if fork is not None:
+                st = side[row_i % len(side)]
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
+                    H.call("adh_conv_wino32_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
+                row += nb
+                row_i += 1
+                continue
             # algorithmic FLOPs of this launch: 2 * virtual pixels * taps * real K * real Nc (Winograd executes 4/9)
             work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
             if wino == "stem":
@@ -487,6 +517,11 @@ class Engine:
                 H.call("adh_conv_forward", C.byref(d), work=work)
             row += nb
             row_i += 1
+        if fork is not None:
+            for st in side:
+                join = torch.cuda.Event()
+                join.record(st)
+                main.wait_event(join)
         return stats, total_blocks
 
     def _wgrad(self, plans, x: Act, g_y: torch.Tensor, gC: int, w: torch.Tensor) -> torch.Tensor:
