@@ -35,6 +35,7 @@
 #define W3_DBG 0   // dev builds of conv_wino32_kernel: 1 = skip the input transform, 2 = skip the contraction, 4 = skip the epilogue, 8 = no staging inside the loop
 #endif
 #include <cstdlib>
+#include <cstring>
 
 #define W2_KC 16
 #define W2_TILES 64
@@ -557,6 +558,12 @@ struct Wino32Geom {
     int ncls, xps;               // input-parity classes (1 or 4), input pixels per virtual pixel
     int ymin[4], xmin[4];        // input pixel of halo (0,0) for virtual pixel (0,0), per class
     int wcls;                    // floats between the packed weights of two classes
+    // merged launch (adh_conv_wino32_forward_multi): `nmerge` single-class descriptors that differ only in their weights, output
+    // parity offset, halo origin (ymin / xmin [m]) and statistics rows run as ONE grid of nmerge * mblocks workgroups
+    int nmerge, mblocks;
+    int m_out_oy[4], m_out_ox[4];
+    const float* m_wp[4];
+    float* m_stats[4];
 };
 
 template <int NT>
@@ -571,7 +578,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    const int bid = blockIdx.x;
+    // merged launch: workgroups [m * mblocks, (m + 1) * mblocks) belong to descriptor m (workgroup-uniform)
+    const int mc = g.nmerge > 1 ? (int)blockIdx.x / g.mblocks : 0;
+    const int bid = (int)blockIdx.x - mc * g.mblocks;
+    const float* const wp_m = g.nmerge > 1 ? g.m_wp[mc] : d.wp;
+    float* const stats_m = g.nmerge > 1 ? g.m_stats[mc] : d.stats;
+    const int out_oy_m = g.nmerge > 1 ? g.m_out_oy[mc] : d.out_oy, out_ox_m = g.nmerge > 1 ? g.m_out_ox[mc] : d.out_ox;
     W3_STAMP(0);
 #ifdef W3_PROF
     if (tid == 0 && bid < 16384) {
@@ -605,8 +617,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     auto slab_geom = [&](int slab) {
         SlabGeom sg;
         const int chunk = slab / g.ncls, c = slab - chunk * g.ncls;
-        sg.iy0 = vy0 * g.xps + g.ymin[c];
-        sg.ix0 = vx0 * g.xps + g.xmin[c];
+        sg.iy0 = vy0 * g.xps + g.ymin[c + mc];
+        sg.ix0 = vx0 * g.xps + g.xmin[c + mc];
         sg.interior = sg.iy0 >= 0 && sg.iy0 + 12 * g.xps < d.IH && sg.ix0 >= 0 && sg.ix0 + 48 * g.xps < d.IW;
         sg.cb = chunk * 64;
         sg.so0 = (sg.iy0 * d.IW + sg.ix0) * d.in_cstride * 4 + sg.cb;
@@ -650,7 +662,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     };
     auto fix_raw = [&](int slab, int buf) {
         const int chunk = slab / g.ncls, c = slab - chunk * g.ncls;
-        const int iy0 = vy0 * g.xps + g.ymin[c], ix0 = vx0 * g.xps + g.xmin[c];
+        const int iy0 = vy0 * g.xps + g.ymin[c + mc], ix0 = vx0 * g.xps + g.xmin[c + mc];
         if (iy0 >= 0 && iy0 + 12 * g.xps < d.IH && ix0 >= 0 && ix0 + 48 * g.xps < d.IW) return;
         float* raw = rawbase + buf * W3_RAW_F;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -705,7 +717,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     const int sw = (l31 >> 1) & 3;
     const int a_lane = (wave * 4) * 1024 + l31 * 16 + ((h ^ sw) * 4);
     const unsigned b_voff = (unsigned)((h * d.NcP + l31) * 16);
-    const float* const b_wave = d.wp + ((int64_t)(wave * 4) * g.KQtot * d.NcP + co0) * 4;
+    const float* const b_wave = wp_m + ((int64_t)(wave * 4) * g.KQtot * d.NcP + co0) * 4;
     const int64_t b_fstride = (int64_t)g.KQtot * d.NcP * 4;
     const int b_kqstride = d.NcP * 4;
 
@@ -871,7 +883,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
                 rowf[r] = vyb + r < d.VH ? 1.f : 0.f;
                 colf[r] = vxb + r < d.VW ? 1.f : 0.f;
             }
-            const int pix0 = (vyb * d.out_sy + d.out_oy) * d.OW + vxb * d.out_sx + d.out_ox;
+            const int pix0 = (vyb * d.out_sy + out_oy_m) * d.OW + vxb * d.out_sx + out_ox_m;
             const unsigned o_vj = (unsigned)(pix0 * d.out_cstride * 4 + cq0 * 4) | chanpen;
             const unsigned r_vj = (unsigned)(pix0 * d.res_cstride * 4 + cq0 * 4) | chanpen;
             f32x4 rres[9];
@@ -906,7 +918,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) {
                     f32x4 v = y[jj] * sc4 + sh4;
-                    if (d.stats) {
+                    if (stats_m) {
                         f32x4 vs = v;
                         if (ragged) {   // pixels outside the virtual grid do not count (a real, workgroup-uniform branch)
                             vs = v * (rowf[i] * colf[jj]);
@@ -926,7 +938,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
             }
         }
         if (j == 1) W3_STAMP(21);
-        if (d.stats) {
+        if (stats_m) {
             // sum over the 8 tiles of this wave (lane bits 3..5), then over the 4 waves through LDS
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -948,7 +960,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
                 float v = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v += red[(which * 4 + r) * 32 + cl];
-                d.stats[((size_t)region * 2 + which) * d.NcP + co0 + j * 32 + cl] = v;
+                stats_m[((size_t)region * 2 + which) * d.NcP + co0 + j * 32 + cl] = v;
             }
         }
     }
@@ -986,6 +998,8 @@ static int wino32_plan(const adh_conv_desc* d, Wino32Geom* g) {
     g->nchunks = d->Cin / W2_KC;
     g->KQtot = d->Cin / 4;
     g->wcls = 16 * g->KQtot * d->NcP * 4;
+    g->nmerge = 1;
+    g->mblocks = 0;
     return 1;
 }
 
@@ -1024,6 +1038,57 @@ extern "C" int adh_conv_wino32_forward(void* stream, const adh_conv_desc* d) {
     if (nt % 3 == 0) return launch_wino32<3>(s, d, g);
     if (nt % 2 == 0) return launch_wino32<2>(s, d, g);
     return launch_wino32<1>(s, d, g);
+}
+
+// Several single-class launches of ONE layer as one grid: the output-parity classes of a transposed convolution / of the data
+// gradient of a k4 s2 convolution (2 x 2-tap forms).  Their grids are not multiples of the CU count (ConvTranspose 384 -> 192:
+// 1056 workgroups = 4.125 rounds of one workgroup per CU), so four launches waste up to four partial rounds; one grid wastes one.
+// The descriptors may differ in wp, out_oy / out_ox, dy0 / dx0 and stats only (checked); n = 2 .. 4.
+extern "C" int adh_conv_wino32_forward_multi(void* stream, const adh_conv_desc* descs, int n) {
+    if (!descs || n < 1 || n > 4) return ADH_E_ARG;
+    if (n == 1) return adh_conv_wino32_forward(stream, descs);
+    Wino32Geom g0;
+    if (!wino32_plan(&descs[0], &g0) || g0.ncls != 1) return ADH_E_UNSUPPORTED;
+    for (int m = 0; m < n; ++m) {
+        const adh_conv_desc* d = &descs[m];
+        Wino32Geom g;
+        if (!wino32_plan(d, &g) || g.ncls != 1) return ADH_E_UNSUPPORTED;
+        if (!d->in || !d->out || !d->wp || d->NcP < d->Cout) return ADH_E_ARG;
+        if (d->out_cstride < d->Cout || (d->residual && d->res_cstride < d->Cout)) return ADH_E_ARG;
+        if ((d->VH - 1) * d->out_sy + d->out_oy >= d->OH || (d->VW - 1) * d->out_sx + d->out_ox >= d->OW || d->out_oy < 0 ||
+            d->out_ox < 0)
+            return ADH_E_ARG;
+        if (((uintptr_t)d->in & 15) || ((uintptr_t)d->wp & 15)) return ADH_E_ARG;
+        adh_conv_desc a = descs[0], b = *d;           // everything but the per-class fields must agree
+        a.wp = b.wp = nullptr; a.stats = b.stats = nullptr;
+        a.out_oy = b.out_oy = 0; a.out_ox = b.out_ox = 0; a.dy0 = b.dy0 = 0; a.dx0 = b.dx0 = 0;
+        if (memcmp(&a, &b, sizeof(a)) != 0 || (!descs[0].stats) != (!d->stats)) return ADH_E_UNSUPPORTED;
+        g0.ymin[m] = g.ymin[0]; g0.xmin[m] = g.xmin[0];
+        g0.m_out_oy[m] = d->out_oy; g0.m_out_ox[m] = d->out_ox;
+        g0.m_wp[m] = d->wp; g0.m_stats[m] = d->stats;
+    }
+    for (int m = n; m < 4; ++m) {
+        g0.ymin[m] = g0.ymin[0]; g0.xmin[m] = g0.xmin[0];
+        g0.m_out_oy[m] = 0; g0.m_out_ox[m] = 0; g0.m_wp[m] = nullptr; g0.m_stats[m] = nullptr;
+    }
+    const int nt = descs[0].NcP / 32;
+    const int NT = nt % 3 == 0 ? 3 : (nt % 2 == 0 ? 2 : 1);
+    g0.ncog = descs[0].NcP / (32 * NT);
+    g0.nmerge = n;
+    g0.mblocks = ((g0.nregions + 7) / 8) * g0.ncog * 8;
+    const int nblocks = n * g0.mblocks;
+    hipStream_t s = (hipStream_t)stream;
+    if (NT == 3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((conv_wino32_kernel<3>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
+    } else if (NT == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((conv_wino32_kernel<2>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((conv_wino32_kernel<1>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
+    }
+    return adh_check_launch();
 }
 
 // U[cls][f = a*4+b][k/4][n][4] = (A g_cls A^T)[a][b], A = [[1,0],[1,1],[1,-1],[0,-1]]; g_cls[ty][tx] is tap

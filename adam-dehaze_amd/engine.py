@@ -37,6 +37,8 @@ USE_BN_FUSED_REDUCE = os.environ.get("ADH_BN_FUSED_REDUCE", "1") != "0"
 # the output-parity class launches of one transposed layer on separate streams (their partial last rounds overlap): measured
 # -0.2 .. -0.4 ms per layer in isolation, +1.5 ms on the whole step -- opt-in
 CLASS_STREAMS = os.environ.get("ADH_CLASS_STREAMS", "0") != "0"
+# ... and as one grid (adh_conv_wino32_forward_multi): what the streams were after, without their events
+MERGE_CLASSES = os.environ.get("ADH_MERGE_CLASSES", "1") != "0"
 _SIDE_STREAMS: Dict[tuple, list] = {}
 
 
@@ -482,6 +484,22 @@ class Engine:
         # The output-parity classes of a transposed form are independent launches whose grids are not multiples of the CU count
         # (e.g. 1056 workgroups = 4.125 rounds of one workgroup per CU: the last round runs on 1/8 of the chip).  On separate
         # streams the next class fills the CUs the previous one's tail leaves idle.
+        if MERGE_CLASSES and 2 <= len(descs) <= 4 and all(w == 32 and dd.KH == 2 for dd, _, _, w in descs):
+            # the output-parity classes of a transposed form as ONE grid: one partial last round of workgroups instead of four
+            for dd, nb, _wp, _w in descs:
+                if stats is not None:
+                    dd.stats = stats.data_ptr() + row * 2 * dd.NcP * 4
+                row += nb
+            arr = (H.ConvDesc * len(descs))(*[dd for dd, _, _, _ in descs])
+            work = sum(2.0 * dd.N * dd.VH * dd.VW * dd.KH * dd.KW * kn for (dd, _, _, _), kn in zip(descs, flops_kn))
+            try:
+                H.call("adh_conv_wino32_forward_multi", arr, len(descs), work=work, work_exec=work * 4.0 / 9.0,
+                       family="adh_conv_wino32_forward")
+                return stats, total_blocks
+            except RuntimeError as e:
+                if "unsupported" not in str(e).lower():
+                    raise
+                row = 0           # descriptors that differ in more than the class fields: one launch each, below
         fork = None
         if CLASS_STREAMS and len(descs) > 1 and all(w == 32 for _, _, _, w in descs):
             main = torch.cuda.current_stream()

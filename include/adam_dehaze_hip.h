@@ -108,6 +108,11 @@ int adh_pack_weights_wino(void* stream, const float* src, const adh_wlayout* L, 
 int adh_conv_wino32_supported(const adh_conv_desc* d);
 int adh_conv_wino32_num_blocks(const adh_conv_desc* d);
 int adh_conv_wino32_forward(void* stream, const adh_conv_desc* d);
+/* descs[0 .. n-1] (n <= 4): the single-class launches of ONE layer -- the four output-parity classes of a ConvTranspose2d k4 s2 p1
+ * or of the data gradient of a Conv2d k4 s2 p1 -- as one grid.  They may differ in wp, out_oy / out_ox, dy0 / dx0 and stats only
+ * (ADH_E_UNSUPPORTED otherwise: launch them one by one).  Same results as n calls of adh_conv_wino32_forward; one partial last
+ * round of workgroups instead of n. */
+int adh_conv_wino32_forward_multi(void* stream, const adh_conv_desc* descs, int n);
 int adh_pack_weights_wino32(void* stream, const float* src, const adh_wlayout* L, float* wp);
 
 /* Winograd F(4x4,3x3) on fp32 MFMA (conv_wino43.hip): the same 3x3 stride-1 pad-1 forms as adh_conv_wino_forward at

@@ -784,3 +784,47 @@ def test_fused_bn_backward_sums_leave_the_block_gradients_unchanged(monkeypatch)
     for k in gr0:
         scale = float(gr0[k].abs().max()) + 1e-12
         assert float((gr1[k] - gr0[k]).abs().max()) < 2e-5 * scale, k
+
+
+@pytest.mark.parametrize("N,Ci,Co,Hh,Ww,train", [(2, 64, 96, 11, 37, True), (1, 384, 192, 16, 24, False), (2, 32, 48, 9, 50, True)])
+def test_merged_class_launch_is_bit_equal(N, Ci, Co, Hh, Ww, train, monkeypatch):
+    """The four output-parity classes of a ConvTranspose2d k4 s2 p1 as ONE grid (adh_conv_wino32_forward_multi) against four
+    launches: same kernel, same arithmetic -- outputs, BatchNorm statistics (train mode: per-class rows of one partials tensor)
+    and the data gradient of the matching Conv2d k4 s2 p1 must be bit-equal; ragged class grids, partial channel tiles."""
+    import adam_dehaze_amd.engine as E
+    from adam_dehaze_amd.engine import BNState
+    dev = torch.device(DEV)
+    gen = torch.Generator().manual_seed(Ci + Co + Hh)
+    x = torch.randn(N, Hh, Ww, Ci, generator=gen).to(dev)
+    w = (torch.randn(Ci, Co, 4, 4, generator=gen) * 0.05).to(dev).requires_grad_(True)
+    wc = (torch.randn(Ci, Co, 4, 4, generator=gen) * 0.05).to(dev).requires_grad_(True)      # Conv2d(Co -> Ci) weights [Ci][Co][4][4]
+    gy = torch.randn(N, Hh, Ww, Ci, generator=gen).to(dev)                                    # gradient wrt that conv's output
+    calls = []
+    real_call = H.call
+
+    def counting(name, *a, **k):
+        calls.append(name)
+        return real_call(name, *a, **k)
+    monkeypatch.setattr(H, "call", counting)
+    res = {}
+    for merged in (False, True):
+        monkeypatch.setattr(E, "MERGE_CLASSES", merged)
+        calls.clear()
+        eng = Engine(dev, record=False)
+        bn = BNState(torch.ones(Co, device=dev), torch.zeros(Co, device=dev), torch.zeros(Co, device=dev), torch.ones(Co, device=dev),
+                     torch.zeros((), device=dev, dtype=torch.long)) if train else None
+        o = eng.conv(Act(x.clone()), w, None, bn, kind="convT", k=4, stride=2, pad=1, relu=True, training=train)
+        gx = torch.empty(N, 2 * Hh, 2 * Ww, _r4(Co), device=dev)
+        eng._run_gather(eng._launch_plan("conv", 4, 2, 1, wc, "dgrad"), Act(gy, Ci), gx, Co, wc)
+        torch.cuda.synchronize()
+        res[merged] = (o.t.clone(), gx.clone(), None if bn is None else bn.running_var.clone(), list(calls))
+    assert res[False][3].count("adh_conv_wino32_forward") >= 4 and "adh_conv_wino32_forward_multi" not in res[False][3]
+    assert res[True][3].count("adh_conv_wino32_forward_multi") >= 1 and "adh_conv_wino32_forward" not in res[True][3]
+    assert torch.equal(res[False][0], res[True][0])
+    assert torch.equal(res[False][1], res[True][1])
+    if train:
+        assert torch.equal(res[False][2], res[True][2])
+
+
+def _r4(c):
+    return (c + 3) // 4 * 4
