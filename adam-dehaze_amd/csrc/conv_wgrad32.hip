@@ -323,9 +323,10 @@ struct H2L {
 static_assert(H2L<64>::MI * H2L<64>::NJ == 6 && H2L<96>::MI * H2L<96>::NJ == 6, "six channel-tile pairs per frequency");
 
 struct Wg32v2Args {
-    int ymin, xmin, xps;
+    int ymin[4], xmin[4], xps;   // halo origin per class
     int S, SX, TY, nsplit, ngroups, ncob;
-    int cls, ncls;
+    int cls, ncls;               // class of this launch (cblocks == 0) ...
+    int cblocks;                 // ... or > 0: all ncls classes in one grid, workgroups [c * cblocks, (c + 1) * cblocks) = class c
 };
 
 template <int IDX>
@@ -457,7 +458,11 @@ template <int CI>
 __device__ __forceinline__ void h2_workgroup(const adh_conv_desc& d, const Wg32v2Args& g, float* __restrict__ slab, float* smem) {
     typedef H2L<CI> L;
     constexpr int CO = L::CO, MI = L::MI, NJ = L::NJ;
-    const int bid = blockIdx.x;
+    // one grid for all classes (Conv2d k4 s2: four kernel-parity classes): 4 x cblocks workgroups pack into whole rounds of the
+    // chip where four launches of one (not quite full) round each do not
+    const int cls = g.cblocks > 0 ? (int)blockIdx.x / g.cblocks : g.cls;
+    const int bid = (int)blockIdx.x - (g.cblocks > 0 ? cls * g.cblocks : 0);
+    const int ymin = g.ymin[cls], xmin = g.xmin[cls];
     const int q2 = bid >> 3;
     const int grp = q2 % g.ngroups;
     const int split = (q2 / g.ngroups) * 8 + (bid & 7);
@@ -476,7 +481,7 @@ __device__ __forceinline__ void h2_workgroup(const adh_conv_desc& d, const Wg32v
 
     const int xcs = d.in_cstride * 4 * g.xps, gcs = d.out_cstride * 4 * d.out_sx;
     const int xrs = d.IW * d.in_cstride * 4 * g.xps, grs = d.OW * d.out_cstride * 4 * d.out_sy;
-    const float* xbase = d.in + ((int64_t)g.ymin * d.IW + g.xmin) * d.in_cstride + ci0;
+    const float* xbase = d.in + ((int64_t)ymin * d.IW + xmin) * d.in_cstride + ci0;
     const float* gbase = d.out + ((int64_t)d.out_oy * d.OW + d.out_ox) * d.out_cstride + co0;
     const int64_t ximg = (int64_t)d.IH * d.IW * d.in_cstride, gimg = (int64_t)d.OH * d.OW * d.out_cstride;
     // per-lane global offsets of the pieces.  64-channel operand: piece = 4 pixels x 16 quads, one pattern.  96-channel operand: a
@@ -514,8 +519,8 @@ __device__ __forceinline__ void h2_workgroup(const adh_conv_desc& d, const Wg32v
         t.gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gbase + n * gimg), 0, 0x7fffffff, 0x00020000);
         t.vy0 = ty * 3;
         t.vx0 = sx * 24;
-        t.iy0 = t.vy0 * g.xps + g.ymin;
-        t.ix0 = t.vx0 * g.xps + g.xmin;
+        t.iy0 = t.vy0 * g.xps + ymin;
+        t.ix0 = t.vx0 * g.xps + xmin;
         t.xb = __builtin_amdgcn_readfirstlane((unsigned)(t.vy0 * xrs + t.vx0 * xcs));
         t.gb = __builtin_amdgcn_readfirstlane((unsigned)(t.vy0 * grs + t.vx0 * gcs));
         t.interior = t.iy0 >= 0 && t.iy0 + 3 * g.xps < d.IH && t.ix0 >= 0 && t.ix0 + 27 * g.xps < d.IW &&
@@ -672,7 +677,7 @@ __device__ __forceinline__ void h2_workgroup(const adh_conv_desc& d, const Wg32v
 
     // partial result -> slab[split][cls][f = 4 * wave + b][KP][NcP]
     const int KP = d.Cin;
-    float* sbase = slab + (((size_t)split * g.ncls + g.cls) * 16 + wave * 4) * KP * d.NcP;
+    float* sbase = slab + (((size_t)split * g.ncls + cls) * 16 + wave * 4) * KP * d.NcP;
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -795,6 +800,15 @@ extern "C" int adh_conv_wgrad_wino32_classes(const adh_conv_desc* d) {
     return wgrad32_plan(d, 1, &p) ? p.ncls : 0;
 }
 
+// kernel launches one adh_conv_wgrad_wino32 call makes: the classes of a k4 s2 form share one grid on conv_wgrad32v2_kernel
+// (the caller's split count then sees classes x groups workgroup groups in that grid)
+extern "C" int adh_conv_wgrad_wino32_launches(const adh_conv_desc* d) {
+    if (!d) return ADH_E_ARG;
+    Wg32Plan p;
+    if (!wgrad32_plan(d, 1, &p)) return 0;
+    return p.v2 ? 1 : p.ncls;
+}
+
 extern "C" int adh_conv_wgrad_wino32_tiles(const adh_conv_desc* d) {
     if (!d) return ADH_E_ARG;
     Wg32Plan p;
@@ -814,16 +828,17 @@ extern "C" int adh_conv_wgrad_wino32(void* stream, const adh_conv_desc* d, float
                                   160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad32v2c96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
-        for (int c = 0; c < p.ncls; ++c) {
-            Wg32v2Args a;
-            a.ymin = p.cls[c].ymin; a.xmin = p.cls[c].xmin; a.xps = p.cls[c].xps;
-            a.S = p.S; a.SX = p.SX; a.TY = p.TY; a.nsplit = nsplit; a.ngroups = p.base.ngroups; a.ncob = p.ncob;
-            a.cls = c; a.ncls = p.ncls;
-            if (p.v2 == 64) hipLaunchKernelGGL(conv_wgrad32v2_kernel, dim3(nblocks), dim3(256), H2L<64>::LDS_BYTES, s, *d, a, slab);
-            else hipLaunchKernelGGL(conv_wgrad32v2c96_kernel, dim3(nblocks), dim3(256), H2L<96>::LDS_BYTES, s, *d, a, slab);
-            const int rc = adh_check_launch();
-            if (rc) return rc;
-        }
+        Wg32v2Args a;
+        for (int c = 0; c < 4; ++c) { a.ymin[c] = p.cls[c < p.ncls ? c : 0].ymin; a.xmin[c] = p.cls[c < p.ncls ? c : 0].xmin; }
+        a.xps = p.cls[0].xps;
+        a.S = p.S; a.SX = p.SX; a.TY = p.TY; a.nsplit = nsplit; a.ngroups = p.base.ngroups; a.ncob = p.ncob;
+        a.cls = 0; a.ncls = p.ncls;
+        a.cblocks = p.ncls > 1 ? nblocks : 0;            // all classes of a k4 s2 form in one grid
+        const int grid = nblocks * p.ncls;
+        if (p.v2 == 64) hipLaunchKernelGGL(conv_wgrad32v2_kernel, dim3(grid), dim3(256), H2L<64>::LDS_BYTES, s, *d, a, slab);
+        else hipLaunchKernelGGL(conv_wgrad32v2c96_kernel, dim3(grid), dim3(256), H2L<96>::LDS_BYTES, s, *d, a, slab);
+        const int rc = adh_check_launch();
+        if (rc) return rc;
         return ADH_OK;
     }
     for (int c = 0; c < p.ncls; ++c) {

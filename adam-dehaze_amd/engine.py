@@ -616,8 +616,10 @@ class Engine:
                 # the 2x2-tap forms (k4 s2 / transposed layers): accumulate in the F(3x3,2x2) domain, 16 frequency slabs per
                 # class, A^T(.)A in the reduce
                 ncls = H.value("adh_conv_wgrad_wino32_classes", C.byref(d))
-                nsplit = _rows_nsplit(w32_groups, H.value("adh_conv_wgrad_wino32_tiles", C.byref(d)), launches=ncls,
-                                      slab_bytes=ncls * 16 * KP * NcP * 4, tile_us=5.0,
+                # (conv_wgrad32v2_kernel runs the classes of a k4 s2 form in ONE grid: classes x groups workgroup groups)
+                launches = max(1, H.value("adh_conv_wgrad_wino32_launches", C.byref(d)))
+                nsplit = _rows_nsplit(w32_groups * ncls // launches, H.value("adh_conv_wgrad_wino32_tiles", C.byref(d)),
+                                      launches=launches, slab_bytes=ncls * 16 * KP * NcP * 4, tile_us=5.0,
                                       max_splits=max(1, _SLAB_BUDGET // (ncls * 16 * KP * NcP * 4)))
                 while nsplit * ncls * 16 * KP * NcP * 4 > (1 << 30) and nsplit > 1:
                     nsplit //= 2

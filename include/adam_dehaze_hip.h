@@ -204,6 +204,9 @@ int adh_wgrad_reduce_wino(void* stream, float* slab /* scratch: split 0 receives
 int adh_conv_wgrad_wino32_groups(const adh_conv_desc* d);
 int adh_conv_wgrad_wino32_classes(const adh_conv_desc* d);
 int adh_conv_wgrad_wino32_tiles(const adh_conv_desc* d);
+/* kernel launches per adh_conv_wgrad_wino32 call: 1 when the classes share one grid (then classes * groups workgroup groups per
+ * pixel split run together), else the class count */
+int adh_conv_wgrad_wino32_launches(const adh_conv_desc* d);
 int adh_conv_wgrad_wino32(void* stream, const adh_conv_desc* d, float* slab, int nsplit);
 int adh_wgrad_reduce_wino32(void* stream, float* slab /* scratch: split 0 receives the sum */, int nsplit,
                             const adh_conv_desc* d, int KP, int NcP, const adh_wlayout* L, float* dst, int accumulate);
