@@ -89,6 +89,7 @@ _SIGNATURES = {
     "adh_conv_wgrad_wino32_tiles": [PD],
     "adh_conv_wgrad_wino32_launches": [PD],
     "adh_conv_wgrad_wino32": [vp, PD, vp, i32],
+    "adh_conv_wgrad_wino32_multi": [vp, PD, i32, vp, i32],
     "adh_wgrad_reduce_wino32": [vp, vp, i32, PD, i32, i32, PL, vp, i32],
     "adh_conv_wgrad_small_slabs": [PD],
     "adh_conv_wgrad_small": [vp, PD, vp, i32, i32],

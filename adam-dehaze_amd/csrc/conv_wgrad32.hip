@@ -25,6 +25,7 @@
 // TN = 3.  Ragged grids (the class grids are 2^k sized, 3 and 48 are not): dY pixels beyond the grid are zero-filled,
 // halo pixels beyond the image too.
 #include "common.h"
+#include <cstring>
 #include <cstdlib>
 #include <type_traits>
 
@@ -327,6 +328,7 @@ struct Wg32v2Args {
     int S, SX, TY, nsplit, ngroups, ncob;
     int cls, ncls;               // class of this launch (cblocks == 0) ...
     int cblocks;                 // ... or > 0: all ncls classes in one grid, workgroups [c * cblocks, (c + 1) * cblocks) = class c
+    int64_t gofs[4];             // float offset of dY's pixel (out_oy, out_ox) per class (the class descriptors of a transposed layer differ in it)
 };
 
 template <int IDX>
@@ -482,7 +484,7 @@ __device__ __forceinline__ void h2_workgroup(const adh_conv_desc& d, const Wg32v
     const int xcs = d.in_cstride * 4 * g.xps, gcs = d.out_cstride * 4 * d.out_sx;
     const int xrs = d.IW * d.in_cstride * 4 * g.xps, grs = d.OW * d.out_cstride * 4 * d.out_sy;
     const float* xbase = d.in + ((int64_t)ymin * d.IW + xmin) * d.in_cstride + ci0;
-    const float* gbase = d.out + ((int64_t)d.out_oy * d.OW + d.out_ox) * d.out_cstride + co0;
+    const float* gbase = d.out + g.gofs[cls] + co0;
     const int64_t ximg = (int64_t)d.IH * d.IW * d.in_cstride, gimg = (int64_t)d.OH * d.OW * d.out_cstride;
     // per-lane global offsets of the pieces.  64-channel operand: piece = 4 pixels x 16 quads, one pattern.  96-channel operand: a
     // piece is 1 KB of 384-byte pixels, three patterns; pieces k, k + 3 are 8 pixels apart
@@ -834,6 +836,7 @@ extern "C" int adh_conv_wgrad_wino32(void* stream, const adh_conv_desc* d, float
         a.S = p.S; a.SX = p.SX; a.TY = p.TY; a.nsplit = nsplit; a.ngroups = p.base.ngroups; a.ncob = p.ncob;
         a.cls = 0; a.ncls = p.ncls;
         a.cblocks = p.ncls > 1 ? nblocks : 0;            // all classes of a k4 s2 form in one grid
+        for (int c = 0; c < 4; ++c) a.gofs[c] = ((int64_t)d->out_oy * d->OW + d->out_ox) * d->out_cstride;
         const int grid = nblocks * p.ncls;
         if (p.v2 == 64) hipLaunchKernelGGL(conv_wgrad32v2_kernel, dim3(grid), dim3(256), H2L<64>::LDS_BYTES, s, *d, a, slab);
         else hipLaunchKernelGGL(conv_wgrad32v2c96_kernel, dim3(grid), dim3(256), H2L<96>::LDS_BYTES, s, *d, a, slab);
@@ -915,6 +918,44 @@ __global__ void wgrad_reduce_wino32_kernel(const float* __restrict__ slab, int n
     }
 }
 
+
+// The class descriptors of ONE transposed layer (2 x 2-tap forms that differ in out_oy / out_ox and dy0 / dx0 only) as one grid of
+// conv_wgrad32v2_kernel: slab[split][m][16][Cin][NcP], the splits are summed here (into split 0); the caller then runs
+// adh_wgrad_reduce_wino32(slab + m * 16 * Cin * NcP, nsplit = 1, &descs[m], ..) per class.  ADH_E_UNSUPPORTED: launch them one by one.
+extern "C" int adh_conv_wgrad_wino32_multi(void* stream, const adh_conv_desc* descs, int n, float* slab, int nsplit) {
+    if (!descs || !slab || n < 2 || n > 4 || nsplit < 1) return ADH_E_ARG;
+    Wg32Plan p0;
+    if (!wgrad32_plan(&descs[0], nsplit, &p0) || !p0.v2 || p0.ncls != 1) return ADH_E_UNSUPPORTED;
+    Wg32v2Args a;
+    for (int m = 0; m < n; ++m) {
+        const adh_conv_desc* d = &descs[m];
+        Wg32Plan p;
+        if (!d->in || !d->out || ((uintptr_t)d->in & 15) || ((uintptr_t)d->out & 15)) return ADH_E_ARG;
+        if (!wgrad32_plan(d, nsplit, &p) || p.v2 != p0.v2 || p.ncls != 1 || p.S != p0.S || p.SX != p0.SX || p.TY != p0.TY ||
+            p.cls[0].xps != p0.cls[0].xps)
+            return ADH_E_UNSUPPORTED;
+        adh_conv_desc x = descs[0], y = *d;
+        x.out_oy = y.out_oy = 0; x.out_ox = y.out_ox = 0; x.dy0 = y.dy0 = 0; x.dx0 = y.dx0 = 0;
+        x.wp = y.wp = nullptr; x.stats = y.stats = nullptr;
+        if (memcmp(&x, &y, sizeof(x)) != 0) return ADH_E_UNSUPPORTED;
+        a.ymin[m] = p.cls[0].ymin; a.xmin[m] = p.cls[0].xmin;
+        a.gofs[m] = ((int64_t)d->out_oy * d->OW + d->out_ox) * d->out_cstride;
+    }
+    for (int m = n; m < 4; ++m) { a.ymin[m] = a.ymin[0]; a.xmin[m] = a.xmin[0]; a.gofs[m] = a.gofs[0]; }
+    const int nblocks = ((nsplit + 7) / 8) * p0.base.ngroups * 8;
+    a.xps = p0.cls[0].xps;
+    a.S = p0.S; a.SX = p0.SX; a.TY = p0.TY; a.nsplit = nsplit; a.ngroups = p0.base.ngroups; a.ncob = p0.ncob;
+    a.cls = 0; a.ncls = n; a.cblocks = nblocks;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad32v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad32v2c96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (p0.v2 == 64) hipLaunchKernelGGL(conv_wgrad32v2_kernel, dim3(nblocks * n), dim3(256), H2L<64>::LDS_BYTES, s, descs[0], a, slab);
+    else hipLaunchKernelGGL(conv_wgrad32v2c96_kernel, dim3(nblocks * n), dim3(256), H2L<96>::LDS_BYTES, s, descs[0], a, slab);
+    const int rc = adh_check_launch();
+    if (rc) return rc;
+    if (nsplit > 1) adh_wgrad_sum_splits(s, slab, nsplit, (int64_t)n * 16 * descs[0].Cin * descs[0].NcP / 4);
+    return adh_check_launch();
+}
 
 extern "C" int adh_wgrad_reduce_wino32(void* stream, float* slab, int nsplit, const adh_conv_desc* d, int KP, int NcP,
                                        const adh_wlayout* L, float* dst, int accumulate) {

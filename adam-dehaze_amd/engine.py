@@ -561,6 +561,9 @@ class Engine:
                     H.call("adh_wgrad_reduce_small", slab.data_ptr(), nslabs, 8, NcP, C.byref(L), dw.data_ptr(), 0)
                     return dw
             return self._wgrad_packed_stem(gm, x, g_y, gC, w, dw)
+        if MERGE_CLASSES and USE_WINOGRAD and 2 <= len(plans) <= 4 and all(gm["KH"] == 2 and gm["KW"] == 2 for _, gm in plans) \
+                and self._wgrad_merged_classes(plans, x, g_y, gC, dw):
+            return dw
         for L, gm in plans:
             NcP = _round_up(L.Nc, 32)
             KP = _round_up(L.K, 32)
@@ -643,6 +646,46 @@ class Engine:
                    work=2.0 * d.N * d.VH * d.VW * T * L.K * L.Nc)
             H.call("adh_wgrad_reduce", slab.data_ptr(), nslabs, KP, NcP, C.byref(L), dw.data_ptr(), 0)
         return dw
+
+    def _wgrad_merged_classes(self, plans, x: Act, g_y: torch.Tensor, gC: int, dw: torch.Tensor) -> bool:
+        """The output-parity classes of a transposed layer through ONE launch of conv_wgrad32v2_kernel
+        (adh_conv_wgrad_wino32_multi): classes x groups workgroup groups pack into whole rounds of the chip.  False: not its
+        shapes -- the caller launches the classes one by one."""
+        descs = []
+        for L, gm in plans:
+            NcP = _round_up(L.Nc, 32)
+            if gm["vgrid"] == "in":
+                VH = (g_y.shape[1] - gm["out_o"][0] + 1) // 2
+                VW = (g_y.shape[2] - gm["out_o"][1] + 1) // 2
+            else:
+                VH, VW = g_y.shape[1], g_y.shape[2]
+            descs.append(self._conv_desc(x, _round_up(L.K, 4), g_y, _round_up(gC, 4), NcP, VH, VW, gm["KH"], gm["KW"], gm["in_s"],
+                                         gm["out_s"], gm["out_o"], gm["dy0"], gm["dx0"], gm["dstep"]))
+        L0 = plans[0][0]
+        d0, n = descs[0], len(descs)
+        KP, NcP = d0.Cin, d0.NcP
+        if any(L.K != L0.K or L.Nc != L0.Nc for L, _ in plans) or KP != _round_up(L0.K, 32):
+            return False
+        groups = H.value("adh_conv_wgrad_wino32_groups", C.byref(d0))
+        if not groups or H.value("adh_conv_wgrad_wino32_classes", C.byref(d0)) != 1:
+            return False
+        plane = 16 * KP * NcP
+        nsplit = _rows_nsplit(groups * n, H.value("adh_conv_wgrad_wino32_tiles", C.byref(d0)), slab_bytes=n * plane * 4,
+                              tile_us=5.0, max_splits=max(1, _SLAB_BUDGET // (n * plane * 4)))
+        slab = self._f(nsplit * n * plane)
+        arr = (H.ConvDesc * n)(*descs)
+        work = sum(2.0 * dd.N * dd.VH * dd.VW * 4 * L.K * L.Nc for dd, (L, _) in zip(descs, plans))
+        try:
+            H.call("adh_conv_wgrad_wino32_multi", arr, n, slab.data_ptr(), nsplit, work=work, work_exec=work * 4.0 / 9.0,
+                   family="adh_conv_wgrad_wino32")
+        except RuntimeError as e:
+            if "unsupported" not in str(e).lower():
+                raise
+            return False
+        for m, (L, _) in enumerate(plans):     # the splits are summed: one class plane each
+            H.call("adh_wgrad_reduce_wino32", slab.data_ptr() + m * plane * 4, 1, C.byref(descs[m]), KP, NcP, C.byref(L),
+                   dw.data_ptr(), 0)
+        return True
 
     def _wgrad_packed_stem(self, gm, x: Act, g_y: torch.Tensor, gC: int, w: torch.Tensor, dw: torch.Tensor):
         """7x7 stem (Cin 3 stored as NHWC8): 4 adjacent pixels x 8 channels fill one 32-wide MFMA row tile, so a

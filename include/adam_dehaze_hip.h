@@ -204,6 +204,11 @@ int adh_wgrad_reduce_wino(void* stream, float* slab /* scratch: split 0 receives
 int adh_conv_wgrad_wino32_groups(const adh_conv_desc* d);
 int adh_conv_wgrad_wino32_classes(const adh_conv_desc* d);
 int adh_conv_wgrad_wino32_tiles(const adh_conv_desc* d);
+/* The class descriptors of ONE transposed layer (n = 2 .. 4 single-class descriptors that differ in out_oy / out_ox and dy0 / dx0
+ * only) as one grid: slab[nsplit][n][16][Cin][NcP]; the splits are summed into split 0 by this call, the caller then runs
+ * adh_wgrad_reduce_wino32(slab + m * 16 * Cin * NcP, 1, &descs[m], ...) for every class m.  ADH_E_UNSUPPORTED when the shapes are
+ * not conv_wgrad32v2_kernel's or the descriptors differ in more: use adh_conv_wgrad_wino32 per descriptor. */
+int adh_conv_wgrad_wino32_multi(void* stream, const adh_conv_desc* descs, int n, float* slab, int nsplit);
 /* kernel launches per adh_conv_wgrad_wino32 call: 1 when the classes share one grid (then classes * groups workgroup groups per
  * pixel split run together), else the class count */
 int adh_conv_wgrad_wino32_launches(const adh_conv_desc* d);

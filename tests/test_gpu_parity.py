@@ -828,3 +828,35 @@ def test_merged_class_launch_is_bit_equal(N, Ci, Co, Hh, Ww, train, monkeypatch)
 
 def _r4(c):
     return (c + 3) // 4 * 4
+
+
+@pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 128, 192, 12, 40), (1, 96, 64, 24, 48), (1, 384, 96, 16, 64)])
+def test_merged_class_weight_gradient(N, Ci, Co, Hh, Ww, monkeypatch):
+    """ConvTranspose2d k4 s2 p1 weight gradient with its four output-parity classes in ONE grid of conv_wgrad32v2_kernel
+    (adh_conv_wgrad_wino32_multi) against four launches and against the fp64 definition (both channel splits of the kernel)."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(Ci + Co + Ww)
+    x = torch.randn(N, Hh, Ww, Ci, generator=g)
+    gy = torch.randn(N, 2 * Hh, 2 * Ww, Co, generator=g)
+    w = torch.zeros(Ci, Co, 4, 4, device=DEV, requires_grad=True)
+    wr = torch.zeros(Ci, Co, 4, 4, dtype=torch.float64, requires_grad=True)
+    (F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wr, stride=2, padding=1) * gy.permute(0, 3, 1, 2).double()).sum().backward()
+    ref = wr.grad
+    calls = []
+    real_call = H.call
+
+    def counting(name, *a, **k):
+        calls.append(name)
+        return real_call(name, *a, **k)
+    monkeypatch.setattr(H, "call", counting)
+    got = {}
+    for merged in (False, True):
+        monkeypatch.setattr(E, "MERGE_CLASSES", merged)
+        calls.clear()
+        eng = Engine(torch.device(DEV), record=False)
+        got[merged] = eng._wgrad(eng._launch_plan("convT", 4, 2, 1, w, "fwd"), Act(x.to(DEV)), gy.to(DEV), Co, w).cpu().double().clone()
+        assert ("adh_conv_wgrad_wino32_multi" in calls) == merged, calls
+        assert calls.count("adh_wgrad_reduce_wino32") == 4
+    scale = float(ref.abs().max())
+    for merged in (False, True):
+        assert float((got[merged] - ref).abs().max()) < 2e-5 * scale
