@@ -31,6 +31,7 @@ USE_WINO43 = {"0": False, "1": True}.get(os.environ.get("ADH_WINO43", "1"), os.e
 USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "1") != "0"
 W43_WGRAD_ROUNDS = int(os.environ.get("ADH_W43_WGRAD_ROUNDS", "4"))   # dev: rounds of workgroups the pixel splits may form
 USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"
+USE_FEWOUT = os.environ.get("ADH_FEWOUT", "1") != "0"               # conv_fewout.hip for the <= 4-output-channel 3x3 heads
 # BatchNorm-backward sums of a ConvBlock taken in the epilogue of its single consumer's data-gradient launch
 # (adh_conv_wino43_dgrad_bnred) instead of a bn_bwd_reduce pass over the same tensor (A/B switch)
 USE_BN_FUSED_REDUCE = os.environ.get("ADH_BN_FUSED_REDUCE", "1") != "0"
@@ -406,7 +407,12 @@ class Engine:
             d = self._conv_desc(src, Kp, dst_t, dstC, NcP, VH, VW, gm["KH"], gm["KW"], gm["in_s"], gm["out_s"],
                                 gm["out_o"], gm["dy0"], gm["dx0"], gm["dstep"])
             wino = False
-            if USE_WINOGRAD and (not _WINO_ONLY or _WINO_ONLY == ("dgrad" if gm["dstep"] == -1 else "fwd")) \
+            if L.Nc <= 4 and gm["KH"] == 3 and gm["KW"] == 3 and residual is None and not want_stats and bnred is None and \
+                    USE_FEWOUT and gm["dstep"] == 1 and H.value("adh_conv_fewout_supported", C.byref(d)):
+                # at most four output channels (the reconstruction heads): one pixel per thread instead of a 32-wide MFMA tile
+                wino = "fewout"
+                wp = self._packed("adh_pack_weights_fewout", w, L, 9 * Kp * 4)
+            if not wino and USE_WINOGRAD and (not _WINO_ONLY or _WINO_ONLY == ("dgrad" if gm["dstep"] == -1 else "fwd")) \
                     and gm["KH"] == 3 and gm["KW"] == 3 and gm["in_s"] == 1 and gm["out_s"] == 1 and Kp % 16 == 0 \
                     and (gm["dy0"], gm["dx0"], gm["dstep"]) in ((-1, -1, 1), (1, 1, -1)):
                 Lw = L
@@ -461,8 +467,9 @@ class Engine:
                 d.residual = residual.data_ptr()
                 d.res_cstride = residual.stride(2)
             d.act = act
-            nb = H.value({32: "adh_conv_wino32_num_blocks", 43: "adh_conv_wino43_num_blocks", True: "adh_conv_wino_num_blocks",
-                          "stem": "adh_conv_stem_num_blocks", False: "adh_conv_num_blocks"}[wino], C.byref(d))
+            nb = 0 if wino == "fewout" else \
+                H.value({32: "adh_conv_wino32_num_blocks", 43: "adh_conv_wino43_num_blocks", True: "adh_conv_wino_num_blocks",
+                         "stem": "adh_conv_stem_num_blocks", False: "adh_conv_num_blocks"}[wino], C.byref(d))
             descs.append((d, nb, wp, wino))
             total_blocks += nb
         if bnred is not None:
@@ -520,7 +527,9 @@ class Engine:
                 continue
             # algorithmic FLOPs of this launch: 2 * virtual pixels * taps * real K * real Nc (Winograd executes 4/9)
             work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
-            if wino == "stem":
+            if wino == "fewout":
+                H.call("adh_conv_fewout_forward", C.byref(d), work=work, family="adh_conv_forward")
+            elif wino == "stem":
                 H.call("adh_conv_stem_forward", C.byref(d), work=work)
             elif wino == 43 and bnred is not None:
                 H.call("adh_conv_wino43_dgrad_bnred", C.byref(d), bnred[2].data_ptr(), work=work, work_exec=work * 0.25,

@@ -144,6 +144,15 @@ int adh_conv_wgrad_small(void* stream, const adh_conv_desc* d, float* slab, int 
 int adh_wgrad_reduce_small(void* stream, const float* slab, int nslabs, int KP, int NcP, const adh_wlayout* L, float* dst,
                            int accumulate);
 
+/* Forward of a 3x3 s1 p1 convolution with at most four output channels (conv_fewout.hip: one output pixel per thread, halo in
+ * LDS, weights through the scalar cache -- the MFMA kernels would pad 3 channels to a 32-wide tile): the reconstruction head
+ * Conv2d(C -> 3) of every branch (/root/reference models/dehazing/high_intensity.py:78, medium_intensity.py, low_intensity.py).
+ * Same descriptor; epilogue scale / shift / ReLU, no residual, no statistics.  Weights: adh_pack_weights_fewout ->
+ * [9][K8 / 4][4][4] floats with K8 = round_up(K, 8) = d->Cin. */
+int adh_conv_fewout_supported(const adh_conv_desc* d);
+int adh_conv_fewout_forward(void* stream, const adh_conv_desc* d);
+int adh_pack_weights_fewout(void* stream, const float* src, const adh_wlayout* L, float* wp);
+
 /* Forward of the 7x7 s1 p3 stem (3 -> 64 / 96 channels on the NHWC8 image; conv_stem.hip): same descriptor and fused
  * epilogue as adh_conv_forward (scale / shift, ReLU, BatchNorm partial statistics; no residual), weights packed by
  * adh_pack_weights_stem -> [7][24][NcP] floats.  Statistics rows = adh_conv_stem_num_blocks(d) (0: not the stem).

@@ -860,3 +860,39 @@ def test_merged_class_weight_gradient(N, Ci, Co, Hh, Ww, monkeypatch):
     scale = float(ref.abs().max())
     for merged in (False, True):
         assert float((got[merged] - ref).abs().max()) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("N,Ci,Co,Hh,Ww,relu", [(2, 48, 3, 37, 70, False), (1, 16, 1, 24, 40, True), (1, 96, 4, 9, 33, False),
+                                                 (1, 24, 3, 512, 96, False)])
+def test_few_output_channel_forward(N, Ci, Co, Hh, Ww, relu, monkeypatch):
+    """conv_fewout.hip (3x3 s1 p1 with <= 4 output channels: the reconstruction heads) against the fp64 definition and the general
+    kernels: ragged tiles, image borders, bias + ReLU epilogue, channel counts 1 / 3 / 4, an output tensor padded to 8 channels
+    whose padding must stay zero."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(Ci * 7 + Co)
+    x = torch.randn(N, Hh, Ww, Ci, generator=g)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    bias = torch.randn(Co, generator=g).to(DEV)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.detach().cpu().double(), bias.cpu().double(), padding=1)
+    if relu:
+        ref = ref.clamp(min=0)
+    calls = []
+    real_call = H.call
+
+    def counting(name, *a, **k):
+        calls.append(name)
+        return real_call(name, *a, **k)
+    monkeypatch.setattr(H, "call", counting)
+    got = {}
+    for few in (True, False):
+        monkeypatch.setattr(E, "USE_FEWOUT", few)
+        calls.clear()
+        eng = Engine(torch.device(DEV), record=False)
+        o = eng.conv(Act(x.to(DEV)), w, bias, None, k=3, stride=1, pad=1, relu=relu)
+        torch.cuda.synchronize()
+        assert ("adh_conv_fewout_forward" in calls) == few
+        assert o.t.shape[3] == 8 and float(o.t[..., Co:].abs().max()) == 0.0
+        got[few] = o.t[..., :Co].permute(0, 3, 1, 2).cpu().double()
+    scale = float(ref.abs().max())
+    assert float((got[True] - ref).abs().max()) < 2e-6 * scale + 1e-6
+    assert float((got[True] - got[False]).abs().max()) < 2e-5 * scale
