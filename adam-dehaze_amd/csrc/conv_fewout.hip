@@ -137,3 +137,113 @@ extern "C" int adh_pack_weights_fewout(void* stream, const float* src, const adh
                        *L, K4, wp);
     return adh_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The mirror image: 3x3 s1 p1 with at most FOUR input channels (one channel quad) and 4 * COQ output channels -- the data
+// gradient of the reconstruction head (3 -> 48) and the first layer of the guidance branch in eval mode (3 -> 16).  On the
+// MFMA kernels K = 9 x 3 is padded to 9 x 8 and the tile to 32 output channels (Conv 3 -> 48 data gradient at full size:
+// 0.71 ms, write-bound floor 0.16).  Thread = one output pixel, 4 * COQ accumulators, the 10 x 34 x 4-channel halo in LDS
+// (5.4 KB), weights [tap][ci][co] through the scalar cache.  Epilogue: scale / shift / ReLU; no residual, no statistics.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int COQ>
+__global__ __launch_bounds__(256) void conv_fewin_fwd_kernel(const adh_conv_desc d, const f32x4* __restrict__ wp, int tiles_x,
+                                                             int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float halo[FO_HH * FO_HW * 4];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int oy0 = ty * FO_TH, ox0 = tx * FO_TW;
+    const float* in_n = d.in + (size_t)n * d.IH * d.IW * d.in_cstride;
+    for (int p = tid; p < FO_HH * FO_HW; p += 256) {
+        const int hy = p / FO_HW, hx = p - hy * FO_HW;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)iy * d.IW + ix) * d.in_cstride);
+        *reinterpret_cast<f32x4*>(halo + p * 4) = v;
+    }
+    __syncthreads();
+    const int py = tid >> 5, px = tid & 31;
+    f32x4 acc[COQ];
+#pragma unroll
+    for (int q = 0; q < COQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3, dx = t - dy * 3;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(halo + ((py + dy) * FO_HW + px + dx) * 4);
+        const f32x4* wt = wp + (size_t)t * 4 * COQ;          // [ci 4][COQ] float4, wave-uniform
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int q = 0; q < COQ; ++q) acc[q] += x[ci] * wt[ci * COQ + q];
+    }
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy >= d.OH || ox >= d.OW) return;
+    float* o = d.out + ((size_t)n * d.OH * d.OW + (size_t)oy * d.OW + ox) * d.out_cstride;
+#pragma unroll
+    for (int q = 0; q < COQ; ++q) {
+        if (q * 4 < d.Cout) {               // Cout % 4 == 0 (fewin_plan)
+            f32x4 v = acc[q];
+            if (d.scale) v = v * *reinterpret_cast<const f32x4*>(d.scale + q * 4);
+            if (d.shift) v = v + *reinterpret_cast<const f32x4*>(d.shift + q * 4);
+            if (d.act == ADH_ACT_RELU) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+            *reinterpret_cast<f32x4*>(o + q * 4) = v;
+        }
+    }
+}
+
+static int fewin_plan(const adh_conv_desc* d) {
+    static const bool enabled = !(getenv("ADH_FEWOUT") && getenv("ADH_FEWOUT")[0] == '0');
+    if (!enabled || !d) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1) return 0;
+    if (d->out_oy != 0 || d->out_ox != 0 || d->dy0 != -1 || d->dx0 != -1 || d->dstep_y != 1 || d->dstep_x != 1) return 0;
+    if (d->Cin != 8 || d->in_cstride % 4 != 0 || d->in_cstride < 4) return 0;   // K <= 4 real channels in the first quad (the caller checks K)
+    if (d->Cout < 4 || d->Cout > 64 || d->Cout % 4 != 0 || d->out_cstride % 4 != 0 || d->out_cstride < d->Cout) return 0;
+    if (d->VH != d->OH || d->VW != d->OW || d->IH != d->OH || d->IW != d->OW) return 0;
+    if (d->residual || d->stats) return 0;
+    if (((uintptr_t)d->out & 15) || (d->scale && ((uintptr_t)d->scale & 15)) || (d->shift && ((uintptr_t)d->shift & 15))) return 0;
+    return 1;
+}
+
+extern "C" int adh_conv_fewin_supported(const adh_conv_desc* d) { return fewin_plan(d); }
+
+// number of output-channel quads the packed weights / the kernel instantiation carry for `cout` channels: 4, 12 or 16
+static int fewin_coq(int cout) { return cout <= 16 ? 4 : (cout <= 48 ? 12 : 16); }
+
+extern "C" int adh_conv_fewin_forward(void* stream, const adh_conv_desc* d) {
+    if (!fewin_plan(d)) return ADH_E_UNSUPPORTED;
+    if (!d->in || !d->out || !d->wp || ((uintptr_t)d->in & 15) || ((uintptr_t)d->wp & 15)) return ADH_E_ARG;
+    const int tiles_x = adh_ceil_div(d->OW, FO_TW), tiles_y = adh_ceil_div(d->OH, FO_TH);
+    const dim3 grid(tiles_x * tiles_y * d->N), block(256);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(d->wp);
+    hipStream_t s = (hipStream_t)stream;
+    switch (fewin_coq(d->Cout)) {
+        case 4: hipLaunchKernelGGL(conv_fewin_fwd_kernel<4>, grid, block, 0, s, *d, wp, tiles_x, tiles_y); break;
+        case 12: hipLaunchKernelGGL(conv_fewin_fwd_kernel<12>, grid, block, 0, s, *d, wp, tiles_x, tiles_y); break;
+        default: hipLaunchKernelGGL(conv_fewin_fwd_kernel<16>, grid, block, 0, s, *d, wp, tiles_x, tiles_y); break;
+    }
+    return adh_check_launch();
+}
+
+// wp[tap][ci 4][COQ * 4] = W(co, ci, tap) through the layout L (zeros for ci >= L.K, co >= L.Nc), COQ = fewin_coq(L.Nc)
+__global__ void pack_weights_fewin_kernel(const float* __restrict__ src, const adh_wlayout L, int CO, float* __restrict__ wp) {
+    const int total = 9 * 4 * CO;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % CO, ci = (i / CO) & 3, t = i / (4 * CO);
+        const int ty = t / 3, tx = t - ty * 3;
+        float v = 0.f;
+        if (co < L.Nc && ci < L.K)
+            v = src[(int64_t)L.tap_off0 + ty * L.tap_off_sy + tx * L.tap_off_sx + (int64_t)ci * L.stride_k + (int64_t)co * L.stride_n];
+        wp[i] = v;
+    }
+}
+
+extern "C" int adh_pack_weights_fewin(void* stream, const float* src, const adh_wlayout* L, float* wp) {
+    if (!src || !L || !wp || L->K < 1 || L->K > 4 || L->Nc < 1 || L->Nc > 64 || L->KHt != 3 || L->KWt != 3) return ADH_E_ARG;
+    const int CO = fewin_coq(L->Nc) * 4;
+    hipLaunchKernelGGL(pack_weights_fewin_kernel, dim3(adh_min_i(adh_ceil_div(9 * 4 * CO, 256), 64)), dim3(256), 0, (hipStream_t)stream, src, *L,
+                       CO, wp);
+    return adh_check_launch();
+}

@@ -412,6 +412,22 @@ class Engine:
                 # at most four output channels (the reconstruction heads): one pixel per thread instead of a 32-wide MFMA tile
                 wino = "fewout"
                 wp = self._packed("adh_pack_weights_fewout", w, L, 9 * Kp * 4)
+            if not wino and L.K <= 4 and Kp == 8 and 4 <= L.Nc <= 64 and L.Nc % 4 == 0 and gm["KH"] == 3 and gm["KW"] == 3 and \
+                    gm["in_s"] == 1 and gm["out_s"] == 1 and residual is None and not want_stats and USE_FEWOUT and \
+                    (gm["dy0"], gm["dx0"], gm["dstep"]) in ((-1, -1, 1), (1, 1, -1)):
+                # at most four input channels (data gradient of the reconstruction head, 3 -> 48): a per-pixel kernel as well
+                Lw = L
+                dsave = (d.dy0, d.dx0, d.dstep_y, d.dstep_x)
+                if gm["dstep"] == -1:   # data gradient: the same correlation with the filter flipped in both axes
+                    Lw = WLayout(L.K, L.Nc, 3, 3, L.tap_off0 + 2 * L.tap_off_sy + 2 * L.tap_off_sx, -L.tap_off_sy,
+                                 -L.tap_off_sx, L.stride_k, L.stride_n)
+                    d.dy0 = d.dx0 = -1
+                    d.dstep_y = d.dstep_x = 1
+                if H.value("adh_conv_fewin_supported", C.byref(d)):
+                    wino = "fewin"
+                    wp = self._packed("adh_pack_weights_fewin", w, Lw, 9 * 4 * 64)
+                else:
+                    d.dy0, d.dx0, d.dstep_y, d.dstep_x = dsave
             if not wino and USE_WINOGRAD and (not _WINO_ONLY or _WINO_ONLY == ("dgrad" if gm["dstep"] == -1 else "fwd")) \
                     and gm["KH"] == 3 and gm["KW"] == 3 and gm["in_s"] == 1 and gm["out_s"] == 1 and Kp % 16 == 0 \
                     and (gm["dy0"], gm["dx0"], gm["dstep"]) in ((-1, -1, 1), (1, 1, -1)):
@@ -467,7 +483,7 @@ class Engine:
                 d.residual = residual.data_ptr()
                 d.res_cstride = residual.stride(2)
             d.act = act
-            nb = 0 if wino == "fewout" else \
+            nb = 0 if wino in ("fewout", "fewin") else \
                 H.value({32: "adh_conv_wino32_num_blocks", 43: "adh_conv_wino43_num_blocks", True: "adh_conv_wino_num_blocks",
                          "stem": "adh_conv_stem_num_blocks", False: "adh_conv_num_blocks"}[wino], C.byref(d))
             descs.append((d, nb, wp, wino))
@@ -529,6 +545,8 @@ class Engine:
             work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
             if wino == "fewout":
                 H.call("adh_conv_fewout_forward", C.byref(d), work=work, family="adh_conv_forward")
+            elif wino == "fewin":
+                H.call("adh_conv_fewin_forward", C.byref(d), work=work, family="adh_conv_forward")
             elif wino == "stem":
                 H.call("adh_conv_stem_forward", C.byref(d), work=work)
             elif wino == 43 and bnred is not None:

@@ -152,6 +152,13 @@ int adh_wgrad_reduce_small(void* stream, const float* slab, int nslabs, int KP, 
 int adh_conv_fewout_supported(const adh_conv_desc* d);
 int adh_conv_fewout_forward(void* stream, const adh_conv_desc* d);
 int adh_pack_weights_fewout(void* stream, const float* src, const adh_wlayout* L, float* wp);
+/* The mirror image: at most four INPUT channels (K <= 4 in the first channel quad of an NHWC8 tensor: d->Cin = 8) and Cout = 4 .. 64
+ * (multiple of 4) output channels: the data gradient of the reconstruction head (3 -> 48; pass the flipped layout, as for the
+ * Winograd data gradients) and the guidance branch's first layer in eval mode.  Weights: adh_pack_weights_fewin ->
+ * [9][4][CO] floats, CO = 16 / 48 / 64 >= Cout. */
+int adh_conv_fewin_supported(const adh_conv_desc* d);
+int adh_conv_fewin_forward(void* stream, const adh_conv_desc* d);
+int adh_pack_weights_fewin(void* stream, const float* src, const adh_wlayout* L, float* wp);
 
 /* Forward of the 7x7 s1 p3 stem (3 -> 64 / 96 channels on the NHWC8 image; conv_stem.hip): same descriptor and fused
  * epilogue as adh_conv_forward (scale / shift, ReLU, BatchNorm partial statistics; no residual), weights packed by

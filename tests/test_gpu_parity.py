@@ -896,3 +896,45 @@ def test_few_output_channel_forward(N, Ci, Co, Hh, Ww, relu, monkeypatch):
     scale = float(ref.abs().max())
     assert float((got[True] - ref).abs().max()) < 2e-6 * scale + 1e-6
     assert float((got[True] - got[False]).abs().max()) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("N,K,Co,Hh,Ww,relu", [(2, 3, 48, 37, 70, False), (1, 3, 16, 24, 40, True), (1, 3, 64, 9, 33, True), (1, 1, 8, 17, 64, False)])
+def test_few_input_channel_forward_and_head_data_gradient(N, K, Co, Hh, Ww, relu, monkeypatch):
+    """conv_fewin_fwd_kernel (3x3 s1 p1, <= 4 input channels in the first quad of an 8-channel tensor): forward with bias / ReLU
+    against fp64, and as the data gradient of a Conv2d(Co -> K) head (flipped taps) against autograd in fp64."""
+    import adam_dehaze_amd.engine as E
+    g = torch.Generator().manual_seed(K * 31 + Co)
+    x8 = torch.zeros(N, Hh, Ww, 8)
+    x8[..., :K] = torch.randn(N, Hh, Ww, K, generator=g)
+    w = (torch.randn(Co, K, 3, 3, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    bias = torch.randn(Co, generator=g).to(DEV)
+    ref = F.conv2d(x8[..., :K].permute(0, 3, 1, 2).double(), w.detach().cpu().double(), bias.cpu().double(), padding=1)
+    if relu:
+        ref = ref.clamp(min=0)
+    calls = []
+    real_call = H.call
+
+    def counting(name, *a, **k):
+        calls.append(name)
+        return real_call(name, *a, **k)
+    monkeypatch.setattr(H, "call", counting)
+    eng = Engine(torch.device(DEV), record=False)
+    o = eng.conv(Act(x8.to(DEV), K), w, bias, None, k=3, stride=1, pad=1, relu=relu)
+    torch.cuda.synchronize()
+    assert "adh_conv_fewin_forward" in calls
+    got = o.t[..., :Co].permute(0, 3, 1, 2).cpu().double()
+    assert float((got - ref).abs().max()) < 2e-6 * float(ref.abs().max()) + 1e-6
+    # data gradient of the head Conv2d(Co -> K): input gradient [N, H, W, Co] from the K-channel output gradient
+    wh = (torch.randn(K, Co, 3, 3, generator=g) * 0.2)
+    gy8 = torch.zeros(N, Hh, Ww, 8)
+    gy8[..., :K] = torch.randn(N, Hh, Ww, K, generator=g)
+    xin = torch.zeros(N, Co, Hh, Ww, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xin, wh.double(), padding=1) * gy8[..., :K].permute(0, 3, 1, 2).double()).sum().backward()
+    whd = wh.to(DEV).requires_grad_(True)
+    calls.clear()
+    gx = torch.empty(N, Hh, Ww, Co, device=DEV)
+    eng._run_gather(eng._launch_plan("conv", 3, 1, 1, whd, "dgrad"), Act(gy8.to(DEV), K), gx, Co, whd)
+    torch.cuda.synchronize()
+    assert "adh_conv_fewin_forward" in calls
+    gotg = gx.permute(0, 3, 1, 2).cpu().double()
+    assert float((gotg - xin.grad).abs().max()) < 2e-6 * float(xin.grad.abs().max()) + 1e-6

@@ -28,3 +28,14 @@ for Cin, Cout, alloc in [(3, 16, 8), (16, 16, 16), (16, 1, 16), (48, 3, 48)]:
         calls.clear()
         ms = timeit(lambda: eng._run_gather(plans, x, out, Cout, w))
         print(f"{Cin}->{Cout} k{k} wino={wino}: {ms:.3f} ms via {sorted(set(c for c in calls if 'conv' in c and 'pack' not in c))}")
+# data gradient of the 48 -> 3 head: 3 (8-channel tensor) -> 48
+for few in (True, False):
+    E.USE_FEWOUT = few
+    eng = Engine(dev, record=False)
+    wh = (torch.randn(3, 48, 3, 3, device=dev) * 0.1).requires_grad_(True)
+    gy = torch.zeros(8, 512, 1024, 8, device=dev); gy[..., :3] = torch.randn(8, 512, 1024, 3, device=dev)
+    gx = torch.empty(8, 512, 1024, 48, device=dev)
+    plans = eng._launch_plan("conv", 3, 1, 1, wh, "dgrad")
+    calls.clear()
+    ms = timeit(lambda: eng._run_gather(plans, Act(gy, 3), gx, 48, wh))
+    print(f"dgrad of 48->3 (3->48) fewin={few}: {ms:.3f} ms via {sorted(set(c for c in calls if 'conv' in c and 'pack' not in c))}")
