@@ -143,7 +143,8 @@ extern "C" int adh_pack_weights_fewout(void* stream, const float* src, const adh
 // gradient of the reconstruction head (3 -> 48) and the first layer of the guidance branch in eval mode (3 -> 16).  On the
 // MFMA kernels K = 9 x 3 is padded to 9 x 8 and the tile to 32 output channels (Conv 3 -> 48 data gradient at full size:
 // 0.71 ms, write-bound floor 0.16).  Thread = one output pixel, 4 * COQ accumulators, the 10 x 34 x 4-channel halo in LDS
-// (5.4 KB), weights [tap][ci][co] through the scalar cache.  Epilogue: scale / shift / ReLU; no residual, no statistics.
+// (5.4 KB), weights [tap][ci][co] through the scalar cache.  Epilogue: scale / shift / ReLU, BatchNorm partial statistics for
+// Cout <= 16 (the train-mode first layer of the guidance branch); no residual.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int COQ>
 __global__ __launch_bounds__(256) void conv_fewin_fwd_kernel(const adh_conv_desc d, const f32x4* __restrict__ wp, int tiles_x,
@@ -180,16 +181,43 @@ __global__ __launch_bounds__(256) void conv_fewin_fwd_kernel(const adh_conv_desc
             for (int q = 0; q < COQ; ++q) acc[q] += x[ci] * wt[ci * COQ + q];
     }
     const int oy = oy0 + py, ox = ox0 + px;
-    if (oy >= d.OH || ox >= d.OW) return;
-    float* o = d.out + ((size_t)n * d.OH * d.OW + (size_t)oy * d.OW + ox) * d.out_cstride;
+    const bool inside = oy < d.OH && ox < d.OW;
+    float* o = d.out + ((size_t)n * d.OH * d.OW + (size_t)(inside ? oy : 0) * d.OW + (inside ? ox : 0)) * d.out_cstride;
+    // BatchNorm partial statistics (train-mode ConvBlock): row blockIdx.x of d.stats = [2][NcP] sums over this tile's pixels
+    float* red = halo;                       // [4 waves][2][4 * COQ] after the halo is consumed
+    if (d.stats) __syncthreads();
 #pragma unroll
     for (int q = 0; q < COQ; ++q) {
         if (q * 4 < d.Cout) {               // Cout % 4 == 0 (fewin_plan)
             f32x4 v = acc[q];
             if (d.scale) v = v * *reinterpret_cast<const f32x4*>(d.scale + q * 4);
             if (d.shift) v = v + *reinterpret_cast<const f32x4*>(d.shift + q * 4);
+            if (d.stats) {                  // statistics of the pre-activation output, as the other conv epilogues
+                f32x4 s1 = inside ? v : f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1 * s1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] = wave_sum(s1[e]);
+                    s2[e] = wave_sum(s2[e]);
+                }
+                if ((tid & 63) == 0) {
+                    *reinterpret_cast<f32x4*>(red + ((tid >> 6) * 2 + 0) * 4 * COQ + q * 4) = s1;
+                    *reinterpret_cast<f32x4*>(red + ((tid >> 6) * 2 + 1) * 4 * COQ + q * 4) = s2;
+                }
+            }
             if (d.act == ADH_ACT_RELU) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-            *reinterpret_cast<f32x4*>(o + q * 4) = v;
+            if (inside) *reinterpret_cast<f32x4*>(o + q * 4) = v;
+        }
+    }
+    if (d.stats) {
+        __syncthreads();
+        if (tid < 2 * 4 * COQ) {
+            const int which = tid / (4 * COQ), c = tid - which * 4 * COQ;
+            if (c < d.Cout) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * 4 * COQ + c];
+                d.stats[((size_t)blockIdx.x * 2 + which) * d.NcP + c] = v;
+            }
         }
     }
 }
@@ -202,12 +230,18 @@ static int fewin_plan(const adh_conv_desc* d) {
     if (d->Cin != 8 || d->in_cstride % 4 != 0 || d->in_cstride < 4) return 0;   // K <= 4 real channels in the first quad (the caller checks K)
     if (d->Cout < 4 || d->Cout > 64 || d->Cout % 4 != 0 || d->out_cstride % 4 != 0 || d->out_cstride < d->Cout) return 0;
     if (d->VH != d->OH || d->VW != d->OW || d->IH != d->OH || d->IW != d->OW) return 0;
-    if (d->residual || d->stats) return 0;
+    if (d->residual) return 0;
+    if (d->stats && d->Cout > 16) return 0;     // (statistics: the 16-channel instantiation only -- wave reductions per channel)
     if (((uintptr_t)d->out & 15) || (d->scale && ((uintptr_t)d->scale & 15)) || (d->shift && ((uintptr_t)d->shift & 15))) return 0;
     return 1;
 }
 
 extern "C" int adh_conv_fewin_supported(const adh_conv_desc* d) { return fewin_plan(d); }
+// rows of d->stats the launch writes (one per 8 x 32 tile)
+extern "C" int adh_conv_fewin_num_blocks(const adh_conv_desc* d) {
+    if (!fewin_plan(d)) return ADH_E_UNSUPPORTED;
+    return adh_ceil_div(d->OW, FO_TW) * adh_ceil_div(d->OH, FO_TH) * d->N;
+}
 
 // number of output-channel quads the packed weights / the kernel instantiation carry for `cout` channels: 4, 12 or 16
 static int fewin_coq(int cout) { return cout <= 16 ? 4 : (cout <= 48 ? 12 : 16); }

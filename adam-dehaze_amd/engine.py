@@ -413,7 +413,7 @@ class Engine:
                 wino = "fewout"
                 wp = self._packed("adh_pack_weights_fewout", w, L, 9 * Kp * 4)
             if not wino and L.K <= 4 and Kp == 8 and 4 <= L.Nc <= 64 and L.Nc % 4 == 0 and gm["KH"] == 3 and gm["KW"] == 3 and \
-                    gm["in_s"] == 1 and gm["out_s"] == 1 and residual is None and not want_stats and USE_FEWOUT and \
+                    gm["in_s"] == 1 and gm["out_s"] == 1 and residual is None and (not want_stats or L.Nc <= 16) and USE_FEWOUT and \
                     (gm["dy0"], gm["dx0"], gm["dstep"]) in ((-1, -1, 1), (1, 1, -1)):
                 # at most four input channels (data gradient of the reconstruction head, 3 -> 48): a per-pixel kernel as well
                 Lw = L
@@ -483,9 +483,12 @@ class Engine:
                 d.residual = residual.data_ptr()
                 d.res_cstride = residual.stride(2)
             d.act = act
-            nb = 0 if wino in ("fewout", "fewin") else \
-                H.value({32: "adh_conv_wino32_num_blocks", 43: "adh_conv_wino43_num_blocks", True: "adh_conv_wino_num_blocks",
-                         "stem": "adh_conv_stem_num_blocks", False: "adh_conv_num_blocks"}[wino], C.byref(d))
+            if wino == "fewout":
+                nb = 0
+            else:
+                nb = H.value({32: "adh_conv_wino32_num_blocks", 43: "adh_conv_wino43_num_blocks", True: "adh_conv_wino_num_blocks",
+                              "stem": "adh_conv_stem_num_blocks", "fewin": "adh_conv_fewin_num_blocks",
+                              False: "adh_conv_num_blocks"}[wino], C.byref(d))
             descs.append((d, nb, wp, wino))
             total_blocks += nb
         if bnred is not None:

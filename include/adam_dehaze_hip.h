@@ -155,8 +155,9 @@ int adh_pack_weights_fewout(void* stream, const float* src, const adh_wlayout* L
 /* The mirror image: at most four INPUT channels (K <= 4 in the first channel quad of an NHWC8 tensor: d->Cin = 8) and Cout = 4 .. 64
  * (multiple of 4) output channels: the data gradient of the reconstruction head (3 -> 48; pass the flipped layout, as for the
  * Winograd data gradients) and the guidance branch's first layer in eval mode.  Weights: adh_pack_weights_fewin ->
- * [9][4][CO] floats, CO = 16 / 48 / 64 >= Cout. */
+ * [9][4][CO] floats, CO = 16 / 48 / 64 >= Cout.  Statistics (Cout <= 16 only): adh_conv_fewin_num_blocks(d) rows. */
 int adh_conv_fewin_supported(const adh_conv_desc* d);
+int adh_conv_fewin_num_blocks(const adh_conv_desc* d);
 int adh_conv_fewin_forward(void* stream, const adh_conv_desc* d);
 int adh_pack_weights_fewin(void* stream, const float* src, const adh_wlayout* L, float* wp);
 

@@ -938,3 +938,41 @@ def test_few_input_channel_forward_and_head_data_gradient(N, K, Co, Hh, Ww, relu
     assert "adh_conv_fewin_forward" in calls
     gotg = gx.permute(0, 3, 1, 2).cpu().double()
     assert float((gotg - xin.grad).abs().max()) < 2e-6 * float(xin.grad.abs().max()) + 1e-6
+
+
+def test_few_input_channel_train_mode_statistics(monkeypatch):
+    """ConvBlock(3 -> 16) in train mode through conv_fewin_fwd_kernel: its BatchNorm partial statistics (one row per 8 x 32 tile,
+    ragged tiles masked) must give the same output, running statistics and gradients as the general kernel."""
+    import adam_dehaze_amd.engine as E
+    dev = torch.device(DEV)
+    torch.manual_seed(21)
+    x = torch.rand(2, 3, 37, 70, device=dev)
+    gout = torch.randn(2, 37, 70, 16, device=dev)
+    calls = []
+    real_call = H.call
+
+    def counting(name, *a, **k):
+        calls.append(name)
+        return real_call(name, *a, **k)
+    monkeypatch.setattr(H, "call", counting)
+    res = {}
+    for few in (True, False):
+        monkeypatch.setattr(E, "USE_FEWOUT", few)
+        torch.manual_seed(5)
+        block = ConvBlock(3, 16, 3, 1, 1).to(dev).train()
+        calls.clear()
+        eng = Engine(dev, record=True)
+        o = block.run(eng, eng.image_to_nhwc8(x), True)
+        o.grad = gout.clone()
+        eng.backward()
+        torch.cuda.synchronize()
+        assert ("adh_conv_fewin_forward" in calls) == few
+        names = {id(p): n for n, p in block.named_parameters()}
+        res[few] = (o.t.clone(), {k: v.clone() for k, v in block.state_dict().items() if "running" in k},
+                    {names[k]: g.clone() for k, g in eng.param_grads.items()})
+    assert max_abs(res[True][0], res[False][0]) < 2e-5
+    for k in res[False][1]:
+        assert max_abs(res[True][1][k], res[False][1][k]) < 1e-6, k
+    for k in res[False][2]:
+        scale = float(res[False][2][k].abs().max()) + 1e-12
+        assert float((res[True][2][k] - res[False][2][k]).abs().max()) < 2e-4 * scale, k
