@@ -501,3 +501,28 @@ def test_loss_extractor_warnings_and_weight_loaders():
     lin = {k[len("loss_fn."):]: v for k, v in lsd.items() if k.startswith("loss_fn.lin") and not k.startswith("loss_fn.lins")}
     p2 = L.PerceptualLoss().load_lpips(alex, lin)
     assert p2.weights_loaded and all(torch.equal(p2.state_dict()[k], pl.state_dict()[k]) for k in pl.state_dict())
+
+
+def test_pixel_split_choice_balances_the_xcds():
+    """engine._rows_nsplit: workgroups are dealt to 8 XCDs of 32 CUs and XCD x gets the splits = x mod 8 of every
+    group, so 3 groups x 85 splits (255 workgroups) is TWO rounds -- the choice must keep groups * ceil(nsplit / 8) within whole
+    rounds of 32, respect the slab budget and the tile count, and prefer fewer splits at equal cost."""
+    import adam_dehaze_amd.engine as E
+
+    def rounds(groups, ns):
+        return -(-(groups * (-(-ns // 8))) // 32)
+    # Conv2d k4 s2 96 -> 192 weight gradient: 3 groups, 15136 strips per class, four classes in one grid
+    ns = E._rows_nsplit(3, 15136, launches=4, slab_bytes=4 * 16 * 96 * 192 * 4, tile_us=5.0, max_splits=227)
+    assert ns == 80 and rounds(3, ns) == 1 and rounds(3, 85) == 2
+    # the 3x3 layers of the headline model keep whole rounds
+    for groups, tiles, kp in ((3, 65536, 96), (12, 16384, 192), (48, 4096, 384), (6, 65536, 192)):
+        ns = E._rows_nsplit(groups, tiles, slab_bytes=36 * kp * 96 * 4, tile_us=3.6)
+        blocks_per_xcd = groups * (-(-ns // 8))
+        assert blocks_per_xcd / (rounds(groups, ns) * 32) >= 0.98, (groups, ns)
+    assert E._rows_nsplit(1, 1) == 1
+    assert E._rows_nsplit(48, 5) <= 5                                   # never more splits than tiles
+    assert E._rows_nsplit(3, 100000, max_splits=10) <= 10               # slab budget
+    assert E._rows_nsplit(500, 1000) >= 1
+    # more splits at the same rounds * tiles product cost slab traffic: the smaller count wins
+    a = E._rows_nsplit(3, 15136, launches=4, slab_bytes=4 * 16 * 96 * 192 * 4, tile_us=5.0, max_splits=400)
+    assert a <= 168
