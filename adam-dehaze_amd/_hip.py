@@ -79,6 +79,9 @@ _SIGNATURES = {
     "adh_conv_wino43_forward": [vp, PD],
     "adh_conv_wino43_dgrad_bnred": [vp, PD, vp],
     "adh_pack_weights_wino43": [vp, vp, PL, vp],
+    "adh_conv_wino43_forward_bf16x3": [vp, PD],
+    "adh_conv_wino43_dgrad_bnred_bf16x3": [vp, PD, vp],
+    "adh_pack_weights_wino43_bf16x3": [vp, vp, PL, vp],
     "adh_pack_weights_wino": [vp, vp, PL, vp],
     "adh_conv_wgrad": [vp, PD, vp, i32],
     "adh_conv_wgrad_wino_groups": [PD],

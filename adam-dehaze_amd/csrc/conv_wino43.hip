@@ -55,6 +55,29 @@ static_assert(W4_TABOK + 4 * 640 <= W4_MF, "tables must end before the statistic
 #endif
 #define W4_PIECE_G0 2                              // ... the others one per contraction group from group W4_PIECE_G0 on
 
+// ---- bf16 x 3 contraction (round 4, opt-in: adh_conv_wino43_forward_bf16x3).  Same regions, same transform arithmetic, same
+// epilogue; the contraction runs on v_mfma_f32_32x32x16_bf16 with both operands split EXACTLY into three bf16 planes
+// (x = hi + mid + lo: 8 + 8 + 8 significant bits, each plane the round-to-nearest of what the previous ones left) and the six
+// significant cross terms hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi accumulated in fp32: 162 MFMAs of 32 cycles per chunk
+// and wave instead of 216 of 64 (tools/micro/bf16split.hip: 2.5x at 0.8x the fp32 MFMA's error against fp64; bf16ring.hip:
+// the weight stream keeps up at 1.12 - 1.38x the MFMA floor).  LDS map (bytes):
+//   [0, 73728)        T = pass 1's output [36][32 tiles][4 quads][16 B] (fp32), overwritten in place by pass 2 with the hi
+//                     and mid planes of the same four channels (8 B each; which half holds hi alternates with the tile so
+//                     that the 8-byte operand reads of 32 tiles hit 64 different banks)
+//   [73728, 110592)   lo plane [36][32 tiles][16 ch] bf16
+//   [110592, 151552)  raw halo (as the fp32 form)
+//   [151552, 156672)  slot tables, one entry per slot (the channel quad is added per lane: one VALU per piece is free
+//                     beside bf16 MFMAs)
+#define W4B_VLO_B 73728
+#define W4B_RAW_B 110592
+#define W4B_TAB_B 151552
+#define W4B_LDS_BYTES 156672
+static_assert(W4B_LDS_BYTES >= W4_LDS_BYTES && W4B_LDS_BYTES <= 160 * 1024, "LDS map of the bf16 x 3 variant");
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
 typedef __attribute__((address_space(3))) void* lds_void_ptr4;
 
 #ifdef W4_PROF   // dev build (tools/prof_wino43.sh): per-workgroup s_memtime stamps and the CU each workgroup ran on
@@ -103,6 +126,10 @@ __device__ __forceinline__ void w4_group(f32x16 (&acc)[9 * NT], const f32x4& a, 
 // does contraction group G carry a staging piece?  (dev build W4_DBG & 8: no staging inside the loop)
 constexpr int w4_piece(int G) { return (!(W4_DBG & 8) && G >= W4_PIECE_G0 && G < W4_PIECE_G0 + 10 - W4_P2) ? 1 : 0; }
 constexpr int w4_p2_pieces() { return (W4_DBG & 8) ? 0 : W4_P2; }
+#ifndef W4B_P2
+#define W4B_P2 10                                  // bf16 x 3 form: pieces issued during transform pass 2 (the rest in the contraction)
+#endif
+constexpr int w4b_p2_pieces() { return (W4_DBG & 8) ? 0 : W4B_P2; }
 struct W4Stage {                 // what a contraction group needs to issue one LDS-DMA piece of the NEXT chunk's raw halo
     __amdgpu_buffer_rsrc_t rsrc; // the image
     const int* tab_lane;         // this lane's entry of the offset table; piece u at [256 u]
@@ -212,12 +239,173 @@ __device__ __forceinline__ void w4_chunk(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], 
     }
 }
 
-template <int NT, bool BNRED = false>
+// ------------------------------------------------------------------------------------------------ bf16 x 3 contraction
+// v_cvt_pk_bf16_f32: two floats -> two bf16 (round to nearest even), a in the low half
+__device__ __forceinline__ unsigned w4b_cvt_pk(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ f32x4 w4b_widen(unsigned p01, unsigned p23) {
+    return f32x4{__builtin_bit_cast(float, p01 << 16), __builtin_bit_cast(float, p01 & 0xffff0000u),
+                 __builtin_bit_cast(float, p23 << 16), __builtin_bit_cast(float, p23 & 0xffff0000u)};
+}
+// v = hi + mid + lo exactly (24 significant bits = 3 x 8: every subtraction below is exact)
+// (The residuals as v_dot2c_f32_bf16 -- x + (-1) * hi.lo + 0 * hi.hi, two instructions per pair instead of three -- were tried:
+// the instruction needs three wait states before another VALU instruction may read its result, hipcc's hazard recogniser does
+// not look into inline asm, its builtin does not select on this LLVM, and with the wait states the gain (1 %) is gone.)
+__device__ __forceinline__ void w4b_split(const f32x4& v, u32x2& hi, u32x2& mid, u32x2& lo, float m1) {
+    hi = u32x2{w4b_cvt_pk(v[0], v[1]), w4b_cvt_pk(v[2], v[3])};
+    const f32x4 r = adh_pksub(v, w4b_widen(hi[0], hi[1]), m1);
+    mid = u32x2{w4b_cvt_pk(r[0], r[1]), w4b_cvt_pk(r[2], r[3])};
+    const f32x4 r2 = adh_pksub(r, w4b_widen(mid[0], mid[1]), m1);
+    lo = u32x2{w4b_cvt_pk(r2[0], r2[1]), w4b_cvt_pk(r2[2], r2[3])};
+}
+// pass 2 of the bf16 x 3 form: the six outputs of one frequency row, each split and stored as soon as it exists
+// (hi / mid: 8 bytes each into the thread's own 16-byte slot of T; lo: 8 bytes into the lo plane).  Pointers are in units of
+// 8 bytes; `stride` = 8-byte units between two frequencies of a row (256 for T, 128 for the lo plane).
+// Staging piece pb + i of the next chunk (i < np) rides behind the i-th output, one at a time: a burst backs the address unit up.
+// (No callable parameter: a __global__ template whose body passes a lambda into a function template loses its host stub in hipcc.)
+__device__ __forceinline__ void w4b_bt_split_store(f32x4 (&d)[6], u32x2* p_hi, u32x2* p_mid, u32x2* p_lo, const W4Neg& n, float m1,
+                                                   const W4Stage& st, const int (&vo)[6], int pb, int np) {
+    int nput = 0;
+    auto put = [&](int b, const f32x4& v) {
+        u32x2 hi, mid, lo;
+        w4b_split(v, hi, mid, lo, m1);
+        p_hi[b * 256] = hi;
+        p_mid[b * 256] = mid;
+        p_lo[b * 128] = lo;
+        if (nput < np) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(st.lds) + st.lds_wave + (pb + nput) * 4096), 16,
+                                                     vo[nput], st.cb, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ++nput;
+    };
+    d[0] = W4_A2B2 * d[0] + (n.s2 * d[2] + d[4]);
+    put(0, d[0]);
+    d[5] = W4_A2B2 * d[1] + (n.s2 * d[3] + d[5]);
+    put(5, d[5]);
+    const f32x4 p = n.b2 * d[2] + d[4], r = n.a2 * d[2] + d[4];
+    const f32x4 q = n.b2 * d[1] + d[3], s = n.a2 * d[1] + d[3];
+    put(1, W4_A * q + p);
+    put(2, n.a * q + p);
+    put(3, W4_B * s + r);
+    put(4, n.b * s + r);
+}
+template <bool AGPR>
+__device__ __forceinline__ void w4b_mfma(f32x16& c, const u32x4& a, const u32x4& b) {
+    if constexpr (AGPR) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// the three planes of one (frequency, 32-channel tile) of U: [plane][64 lanes][16 B] = 3 KB contiguous (adh_pack_weights_wino43_bf16x3)
+__device__ __forceinline__ void w4b_load_b(u32x4 (&b)[3], unsigned voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[1]) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(b[2]) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void w4b_wait_b(u32x4 (&b)[3]) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N) : "memory");
+}
+// staging pieces (10 per wave and chunk) carried by contraction group G: one behind the first MFMA of groups 2 .. 11, or,
+// with nine groups per chunk (NT = 1), two in groups 2 .. 6
+template <int NT>
+constexpr int w4b_pieces(int G) {
+    if (W4_DBG & 8) return 0;
+    constexpr int left = 10 - W4B_P2;
+    if (NT == 1) return (G >= 2 && 2 * (G - 2) < left) ? 2 : 0;
+    return (G >= 2 && G - 2 < left) ? 1 : 0;
+}
+template <int NT>
+constexpr int w4b_piece0(int G) { return W4B_P2 + (NT == 1 ? 2 * (G - 2) : G - 2); }
+struct W4BLane {            // this lane's A operand addresses (frequency 0 of its wave)
+    const u32x2* hi0;       // hi plane, channels 8h .. 8h+3 (8-byte units; the other three are this ^ 2, ^ 1, ^ 3)
+    const u32x2* hi1;
+    const u32x2* mid0;
+    const u32x2* mid1;
+    const u32x4* lo;        // lo plane, channels 8h .. 8h+7
+    int quad16;             // (lane & 3) * 16: the channel quad a lane stages
+};
+template <int FI, int P>   // plane P (0 hi, 1 mid, 2 lo) of the wave's frequency FI
+__device__ __forceinline__ void w4b_load_a(u32x4& a, const W4BLane& la) {
+    if constexpr (P == 2) {
+        a = la.lo[FI * 64];
+    } else {
+        const u32x2 q0 = (P ? la.mid0 : la.hi0)[FI * 256], q1 = (P ? la.mid1 : la.hi1)[FI * 256];
+        a = u32x4{q0[0], q0[1], q1[0], q1[1]};
+    }
+}
+// groups G .. 9 NT - 1 of one chunk: group = (frequency G / NT, channel tile G % NT) = three weight loads two groups ahead
+// (ring of three) and six MFMAs on one accumulator tile (back to back on one accumulator is full rate for this instruction), in
+// the order lo*hi | mid*mid, mid*hi | hi*lo, hi*mid, hi*hi.  The V planes are SINGLE buffered (12 registers: next to 27
+// accumulator tiles and the weight ring there is no room for a second set): in the last group of a frequency each plane of
+// the next frequency is requested right behind the last MFMA that reads the old one and is needed four or five MFMAs later.
+template <int NT, int G>
+__device__ __forceinline__ void w4b_groups(f32x16 (&acc)[9 * NT], u32x4 (&a)[3], u32x4 (&bv)[3][3], const W4BLane& la, unsigned b_voff,
+                                           const char* b_chunk, const W4Stage& st) {
+    if constexpr (G < 9 * NT) {
+        constexpr int FI = G / NT, J = G % NT, G2 = G + 2;
+        // (nothing is requested across the chunk boundary: registers an asm load is still filling must not be live through
+        // the transform, where hipcc is free to spill them -- it would store them before they have landed)
+        if constexpr (G2 < 9 * NT) w4b_load_b(bv[G2 % 3], b_voff, b_chunk + G2 * 3072);
+        constexpr int newer = 3 * (9 * NT - 1 - G < 2 ? 9 * NT - 1 - G : 2);
+        constexpr bool nextf = J == NT - 1 && FI + 1 < 9;
+        constexpr int np = w4b_pieces<NT>(G);
+        constexpr bool agpr = w4_in_agpr<NT, FI, J>();
+        u32x4(&b)[3] = bv[G % 3];
+        int vo[np > 0 ? np : 1];
+        if constexpr (np > 0) {   // the pieces' table entries: requested before the wait so that the round trip is over behind the first MFMA
+#pragma unroll
+            for (int e = 0; e < np; ++e) vo[e] = st.tab_lane[64 * (w4b_piece0<NT>(G) + e)];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // newer than this group's weights: the weights of the next two groups and the pieces of the previous two
+        w4b_wait_b<newer + w4b_pieces<NT>(G - 2) + w4b_pieces<NT>(G - 1)>(b);
+        w4b_mfma<agpr>(acc[G], a[2], b[0]);
+        if constexpr (nextf) {
+            __builtin_amdgcn_sched_barrier(0);
+            w4b_load_a<FI + 1, 2>(a[2], la);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (np > 0) {
+#pragma unroll
+            for (int e = 0; e < np; ++e) vo[e] += la.quad16;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < np; ++e)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(st.lds) + st.lds_wave + (w4b_piece0<NT>(G) + e) * 4096),
+                                                         16, vo[e], st.cb, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        w4b_mfma<agpr>(acc[G], a[1], b[1]);
+        w4b_mfma<agpr>(acc[G], a[1], b[0]);
+        if constexpr (nextf) {
+            __builtin_amdgcn_sched_barrier(0);
+            w4b_load_a<FI + 1, 1>(a[1], la);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        w4b_mfma<agpr>(acc[G], a[0], b[2]);
+        w4b_mfma<agpr>(acc[G], a[0], b[1]);
+        w4b_mfma<agpr>(acc[G], a[0], b[0]);
+        if constexpr (nextf) {
+            __builtin_amdgcn_sched_barrier(0);
+            w4b_load_a<FI + 1, 0>(a[0], la);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        w4b_groups<NT, G + 1>(acc, a, bv, la, b_voff, b_chunk, st);
+    }
+}
+
+template <int NT, bool BNRED = false, bool BF3 = false>
 __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc d, const Wino43Geom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // V | raw | slot tables | .. | red ; M aliases V .. red
-    float* const rawbase = lds + W4_VF;
-    int* const tab_off = reinterpret_cast<int*>(lds + W4_TAB);          // [640][4] source byte offset of (slot s, channel quad q) (clamped)
-    int* const tab_ok = reinterpret_cast<int*>(lds + W4_TABOK);         // [640][4] 1 if slot s lies inside the image
+    constexpr int RAW0 = BF3 ? W4B_RAW_B / 4 : W4_VF;                   // float offset of the raw halo
+    float* const rawbase = lds + RAW0;
+    // fp32 form: [640][4] source byte offset of (slot s, channel quad q) (clamped) and [640][4] slot-inside-image flags;
+    // bf16 x 3 form: one entry per slot, [640] offsets then [640] flags
+    int* const tab_off = reinterpret_cast<int*>(lds + (BF3 ? W4B_TAB_B / 4 : W4_TAB));
+    int* const tab_ok = BF3 ? tab_off + 640 : reinterpret_cast<int*>(lds + W4_TABOK);
     float* const red = lds + W4_RED;
 
     const int tid = threadIdx.x;
@@ -258,9 +446,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         const int iyc = adh_min_i(adh_max_i(iy, 0), d.IH - 1), ixc = adh_min_i(adh_max_i(ix, 0), d.IW - 1);
         const int off = (iyc * d.IW + ixc) * xcs;
         typedef int i32x4 __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<i32x4*>(tab_off + 4 * s) = i32x4{off, off + 16, off + 32, off + 48};
         const int ok = (s < W4_SLOTS && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) ? 1 : 0;
-        *reinterpret_cast<i32x4*>(tab_ok + 4 * s) = i32x4{ok, ok, ok, ok};
+        if constexpr (BF3) {
+            tab_off[s] = off;
+            tab_ok[s] = ok;
+        } else {
+            *reinterpret_cast<i32x4*>(tab_off + 4 * s) = i32x4{off, off + 16, off + 32, off + 48};
+            *reinterpret_cast<i32x4*>(tab_ok + 4 * s) = i32x4{ok, ok, ok, ok};
+        }
     }
     const float* in_n = d.in + (int64_t)n * d.IH * d.IW * d.in_cstride;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, 0x7fffffff, 0x00020000);
@@ -269,14 +462,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     // piece k loads (slot 16k + l / 4, quad l % 4): its table entry is tab_off[64 k + l], i.e. one contiguous read per piece
     W4Stage st;
     st.rsrc = xr;
-    st.tab_lane = tab_off + 64 * wave + lane;
+    // (bf16 x 3 form: piece k = 4u + wave, lane l stages slot 16k + l / 4: entry tab_off[64 u + 16 wave + l / 4], + 16 (l % 4) bytes)
+    st.tab_lane = BF3 ? tab_off + 16 * wave + (lane >> 2) : tab_off + 64 * wave + lane;
     st.lds = lds;
-    st.lds_wave = __builtin_amdgcn_readfirstlane((W4_VF + wave * 256) * 4);
+    st.lds_wave = __builtin_amdgcn_readfirstlane((RAW0 + wave * 256) * 4);
     st.cb = 0;
+    constexpr int TABU = BF3 ? 64 : 256;          // table entries between two pieces of a wave
+    const int quad16 = (lane & 3) * 16;
     auto stage_first = [&]() {   // chunk 0 (prologue); the later chunks arrive piece by piece inside the contraction
         int vo[10];   // all table reads first: one LDS round trip instead of ten
 #pragma unroll
-        for (int u = 0; u < 10; ++u) vo[u] = st.tab_lane[256 * u];
+        for (int u = 0; u < 10; ++u) vo[u] = st.tab_lane[TABU * u] + (BF3 ? quad16 : 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 10; ++u)
@@ -289,21 +485,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 10; ++u)
-            if (!st.tab_lane[4 * 640 + 256 * u]) *reinterpret_cast<f32x4*>(raw + u * 1024) = z;
+            if (!st.tab_lane[(BF3 ? 640 : 4 * 640) + TABU * u]) *reinterpret_cast<f32x4*>(raw + u * 1024) = z;
     };
 
     // ------------------------------------------------------------------ input transform (two 1-D passes through LDS)
     // thread = (tile, channel quad); pass 1 item k: patch column c = 2k + (tid >> 7); pass 2 item k: frequency row a = ...
     const int tile_t = (tid >> 2) & 31, trow = tile_t >> 3, tcol = tile_t & 7;
     const int csel = wave >> 1;                                                 // 0 / 1 (wave-uniform)
-    const int vslot_t = tile_t * 16 + ((cq_l ^ ((tile_t >> 1) & 3)) * 4);      // swizzled quad slot inside V[f][tile]
+    // swizzled quad slot inside V[f][tile] (bf16 x 3 form: the slot permutation that makes the 8-byte operand reads conflict-free)
+    const int vslot_t = tile_t * 16 + ((cq_l ^ ((BF3 ? tile_t >> 2 : tile_t >> 1) & 3)) * 4);
     // patch pixel (row i, column c) of this thread's tile sits in raw row 4*trow + i, plane c & 3, index tcol + (c >> 2);
     // slot offset of column c = 2k + csel inside a row: {0, 18, 1} (csel 0: planes 0, 2, 0) / {9, 26, 10} (csel 1)
     // -> two lane pointers (k = 0 and, one slot further, k = 2; k = 1), the patch row is an instruction immediate
     const int rbase_t = ((4 * trow) * W4_ROWSLOTS + tcol) * 16 + cq_l * 4;
-    const int raw_k0 = (W4_VF + rbase_t) / 4 + (csel ? 9 : 0) * 4;      // float4 indices into lds[] (an opaque *pointer* would lose the LDS
-    const int raw_k1 = (W4_VF + rbase_t) / 4 + (csel ? 26 : 18) * 4;    // address space: flat loads; an opaque float index the alignment: b32 reads)
+    const int raw_k0 = (RAW0 + rbase_t) / 4 + (csel ? 9 : 0) * 4;      // float4 indices into lds[] (an opaque *pointer* would lose the LDS
+    const int raw_k1 = (RAW0 + rbase_t) / 4 + (csel ? 26 : 18) * 4;    // address space: flat loads; an opaque float index the alignment: b32 reads)
     const W4Neg negc = w4_neg_constants();
+    const float m1t = adh_opaque(-1.f);
+    constexpr int p2n = BF3 ? w4b_p2_pieces() : w4_p2_pieces();   // pieces of the next chunk's halo issued during pass 2
     auto transform = [&]() {
         // pass 1: T[a][c] = sum_i B^T[a][i] d[i][c] for this thread's three columns c = csel, 2 + csel, 4 + csel
 #pragma unroll
@@ -324,19 +523,34 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         for (int k = 0; k < 3; ++k) {
             const int a = 2 * k + csel;
             f32x4 tt[6];
-            // pieces k, k + 3, .. of the next chunk's halo (the raw buffer's last reader was pass 1): table entries first
-            int vo[4];
+            // pieces of the next chunk's halo (the raw buffer's last reader was pass 1): table entries first.  fp32 form: pieces
+            // k, k + 3, .. behind the row; bf16 x 3 form: as early as possible (they must have landed before the first weight wait
+            // of the contraction, vmcnt being in order), one behind each of the first outputs: six in row 0, four in row 1
+            constexpr int PE = 6;   // (entries used: 6 / 4.  One type for both forms: a discarded `if constexpr` branch inside this lambda is still checked on hipcc's host pass, and a mismatch there silently drops the kernel's host stub)
+            const int pb = BF3 ? (k == 0 ? 0 : (k == 1 ? 6 : 10)) : k, pstep = BF3 ? 1 : 3;
+            int vo[PE];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k + 3 * e < w4_p2_pieces()) vo[e] = st.tab_lane[256 * (k + 3 * e)];
+            for (int e = 0; e < (BF3 ? 6 : 4); ++e)
+                if (pb + pstep * e < p2n) vo[e] = st.tab_lane[TABU * (pb + pstep * e)] + (BF3 ? quad16 : 0);
 #pragma unroll
             for (int c = 0; c < 6; ++c) tt[c] = *reinterpret_cast<const f32x4*>(lds + (a * 6 + c) * (W4_TILES * W4_KC) + vslot_t);
-            w4_bt_store(tt, lds + (a * 6) * (W4_TILES * W4_KC) + vslot_t, W4_TILES * W4_KC, negc);
+            if constexpr (BF3) {
+                // the three planes of the thread's four channels: hi and mid share its slot (hi in the half `hsub` of the tile
+                // says), lo goes to the lo plane [f][tile][(channel half ^ tile bit 3)][quad & 1]
+                const int hsub = ((tile_t >> 1) ^ (tile_t >> 4)) & 1;
+                u32x2* const l8 = reinterpret_cast<u32x2*>(lds);
+                const int slot8 = (a * 6) * 256 + vslot_t / 2;
+                const int lo8 = W4B_VLO_B / 8 + (a * 6) * 128 + tile_t * 4 + (((cq_l >> 1) ^ ((tile_t >> 3) & 1)) * 2) + (cq_l & 1);
+                w4b_bt_split_store(tt, l8 + slot8 + hsub, l8 + slot8 + (hsub ^ 1), l8 + lo8, negc, m1t, st, vo, pb,
+                                   pb >= p2n ? 0 : (p2n - pb < PE ? p2n - pb : PE));
+            } else {
+                w4_bt_store(tt, lds + (a * 6) * (W4_TILES * W4_KC) + vslot_t, W4_TILES * W4_KC, negc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k + 3 * e < w4_p2_pieces())
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + (k + 3 * e) * 4096),
-                                                             16, vo[e], st.cb, 0, 0);
+                for (int e = 0; e < 4; ++e)
+                    if (k + 3 * e < p2n)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + (k + 3 * e) * 4096),
+                                                                 16, vo[e], st.cb, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -352,13 +566,36 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const int64_t b_fstride = (int64_t)g.KQtot * d.NcP * 4;   // floats per frequency
     const int b_kq = d.NcP * 4;                                // floats per channel quad
 
+    // bf16 x 3 form.  A: the lane's tile l31, channels 8h .. 8h+7 of each plane: hi / mid as two 8-byte reads (quads 2h, 2h+1 of the
+    // tile's 64-byte block, slot permutation (tile >> 2) & 3, hi in half ((tile >> 1) ^ (tile >> 4)) & 1 of a slot), lo as one
+    // 16-byte read.  B: adh_pack_weights_wino43_bf16x3's [cog][chunk][36 f][NT][3 planes][64 lanes][16 B]: the 9 NT groups of a wave
+    // and chunk are 27 NT KB contiguous, lane offset 16 * lane
+    W4BLane la;
+    {
+        const int s3 = (l31 >> 2) & 3, hs = ((l31 >> 1) ^ (l31 >> 4)) & 1;
+        const int base8 = (wave * 9) * 256 + l31 * 8 + (((2 * h) ^ s3) * 2) + hs;       // 8-byte units
+        const u32x2* const l8 = reinterpret_cast<const u32x2*>(lds);
+        la.hi0 = l8 + base8;
+        la.hi1 = l8 + (base8 ^ 2);
+        la.mid0 = l8 + (base8 ^ 1);
+        la.mid1 = l8 + (base8 ^ 3);
+        la.lo = reinterpret_cast<const u32x4*>(lds) + W4B_VLO_B / 16 + (wave * 9) * 64 + l31 * 2 + (h ^ ((l31 >> 3) & 1));
+        la.quad16 = quad16;
+    }
+    const unsigned b3_voff = (unsigned)lane * 16u;
+    const size_t b3_cstride = (size_t)36 * NT * 3072;                                   // bytes of U per chunk and channel group
+    const char* const b3_wave = reinterpret_cast<const char*>(d.wp) + ((size_t)cg * g.nchunks * 36 + (size_t)wave * 9) * (NT * 3072);
+
     f32x16 acc[9 * NT];
     f32x4 av[2], bv[3][NT];
+    u32x4 av3[3], bv3[3][3];
 
     // ------------------------------------------------------------------ prologue
     __syncthreads();   // slot tables
-    w4_load_b<NT>(bv[0], b_voff, b_wave);
-    w4_load_b<NT>(bv[1], b_voff, b_wave + b_fstride);
+    if constexpr (!BF3) {
+        w4_load_b<NT>(bv[0], b_voff, b_wave);
+        w4_load_b<NT>(bv[1], b_voff, b_wave + b_fstride);
+    }
     stage_first();
 #pragma unroll
     for (int t = 0; t < 9 * NT; ++t)   // (zeroing 9*NT*16 registers hides under the first DMA round trip)
@@ -381,12 +618,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         if (!(W4_DBG & 1)) transform();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (c == 1) W4_STAMP(10);
+        if constexpr (BF3) {   // the weights of groups 0 and 1: requested here, behind the transform (see w4b_groups)
+            if (!(W4_DBG & 2)) {
+                w4b_load_b(bv3[0], b3_voff, b3_wave + c * b3_cstride);
+                w4b_load_b(bv3[1], b3_voff, b3_wave + c * b3_cstride + 3072);
+            }
+        }
         __builtin_amdgcn_s_barrier();
         if (c == 1) W4_STAMP(11);
         // ---- contraction.  In flight: the weights of groups 0 and 1 and, newer, the pieces pass 2 issued.  The raw buffer is
         // free from pass 2 to the end of the contraction (its only reader is pass 1), so the next chunk's halo lands in it
         // meanwhile; the weight waits of the later groups retire the pieces in order
-        if (!(W4_DBG & 2)) {
+        if constexpr (BF3) {
+            if (!(W4_DBG & 2)) {
+                w4b_load_a<0, 0>(av3[0], la);
+                w4b_load_a<0, 1>(av3[1], la);
+                w4b_load_a<0, 2>(av3[2], la);
+                w4b_groups<NT, 0>(acc, av3, bv3, la, b3_voff, b3_wave + c * b3_cstride, st);
+            }
+        } else if (!(W4_DBG & 2)) {
             const float* b_chunk = b_wave + (int64_t)(c * 4) * b_kq;
             const float* b_next = b_wave + (int64_t)(cn * 4) * b_kq;
             av[0] = *reinterpret_cast<const f32x4*>(vlane);
@@ -409,8 +659,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         __builtin_amdgcn_s_barrier();
         if (c == 1) W4_STAMP(13);
     }
-    w4_wait_b<0, NT>(bv[0]);
-    w4_wait_b<0, NT>(bv[1]);
+    if constexpr (!BF3) {
+        w4_wait_b<0, NT>(bv[0]);
+        w4_wait_b<0, NT>(bv[1]);
+    }
     W4_STAMP(2);
 
     // ---------------------------------------------------------------------- output transform A^T M A + fused epilogue
@@ -629,13 +881,13 @@ extern "C" int adh_conv_wino43_num_blocks(const adh_conv_desc* d) {
     return g.nregions;
 }
 
-template <int NT, bool BNRED = false>
+template <int NT, bool BNRED = false, bool BF3 = false>
 static int launch_wino43(hipStream_t s, const adh_conv_desc* d, Wino43Geom g) {
     g.ncog = d->NcP / (32 * NT);
     const int nblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<NT, BNRED>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<NT, BNRED, BF3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_wino43_kernel<NT, BNRED>), dim3(nblocks), dim3(256), W4_LDS_BYTES, s, *d, g);
+    hipLaunchKernelGGL((conv_wino43_kernel<NT, BNRED, BF3>), dim3(nblocks), dim3(256), BF3 ? W4B_LDS_BYTES : W4_LDS_BYTES, s, *d, g);
     return adh_check_launch();
 }
 
@@ -675,6 +927,36 @@ extern "C" int adh_conv_wino43_dgrad_bnred(void* stream, const adh_conv_desc* d,
     if (nt % 3 == 0) return launch_wino43<3, true>(s, d, g);
     if (nt % 2 == 0) return launch_wino43<2, true>(s, d, g);
     return launch_wino43<1, true>(s, d, g);
+}
+
+// The same two launches with the contraction on v_mfma_f32_32x32x16_bf16 over exact three-plane bf16 splits of both operands
+// (opt-in, ADH_CONTRACT=bf16x3 on the host side; d->wp from adh_pack_weights_wino43_bf16x3).  Same arguments, same results to
+// fp32 rounding: the split is exact and the three dropped cross terms are at 2^-24 of a product.
+extern "C" int adh_conv_wino43_forward_bf16x3(void* stream, const adh_conv_desc* d) {
+    Wino43Geom g;
+    if (!wino43_plan(d, &g)) return ADH_E_UNSUPPORTED;
+    const int rc = wino43_check_args(d);
+    if (rc) return rc;
+    const int nt = d->NcP / 32;
+    hipStream_t s = (hipStream_t)stream;
+    if (nt % 3 == 0) return launch_wino43<3, false, true>(s, d, g);
+    if (nt % 2 == 0) return launch_wino43<2, false, true>(s, d, g);
+    return launch_wino43<1, false, true>(s, d, g);
+}
+
+extern "C" int adh_conv_wino43_dgrad_bnred_bf16x3(void* stream, const adh_conv_desc* d, const float* bn_mean) {
+    Wino43Geom g;
+    if (!wino43_plan(d, &g)) return ADH_E_UNSUPPORTED;
+    const int rc = wino43_check_args(d);
+    if (rc) return rc;
+    if (!d->residual || !d->scale || !d->shift || !d->stats || !bn_mean || d->act != ADH_ACT_NONE) return ADH_E_ARG;
+    if ((uintptr_t)bn_mean & 15) return ADH_E_ARG;
+    g.bn_mean = bn_mean;
+    const int nt = d->NcP / 32;
+    hipStream_t s = (hipStream_t)stream;
+    if (nt % 3 == 0) return launch_wino43<3, true, true>(s, d, g);
+    if (nt % 2 == 0) return launch_wino43<2, true, true>(s, d, g);
+    return launch_wino43<1, true, true>(s, d, g);
 }
 
 // U[f = a*6+b][k/4][n][4] = (G g G^T)[a][b];  row of G for point p: [1, p, p^2] / prod_{q != p} (p - q), for inf: [0, 0, 1]
@@ -727,5 +1009,75 @@ extern "C" int adh_pack_weights_wino43(void* stream, const float* src, const adh
     const int64_t total = (int64_t)KQ * NcP;
     hipLaunchKernelGGL(pack_weights_wino43_kernel, dim3(adh_min_i(adh_ceil_div(total, 128), 4096)), dim3(128), 0,
                        (hipStream_t)stream, src, *L, KQ, NcP, reinterpret_cast<f32x4*>(wp));
+    return adh_check_launch();
+}
+
+// The same U = G g G^T (computed in double, rounded to fp32 exactly as above), split into three bf16 planes and laid out for
+// conv_wino43_kernel<NT, *, true>: [channel group of 32 NT][chunk of 16 k][36 f][NT tiles][3 planes][half h][32 n][8 k] bf16, NT as
+// the launch picks it from NcP.  wp: 36 * Kp * NcP * 6 bytes (Kp = K rounded up to 16, NcP = Nc rounded up to 32).
+__global__ void pack_weights_wino43_bf16x3_kernel(const float* __restrict__ src, const adh_wlayout L, int KO, int NcP, int NT,
+                                                  u32x4* __restrict__ wp) {
+    const int64_t total = (int64_t)KO * NcP;
+    const int nchunks = KO / 2;
+    const double a = W4_A, b = W4_B;
+    const double n0 = a * a * b * b, na = 2.0 * a * a * (a * a - b * b), nb = 2.0 * b * b * (b * b - a * a);
+    const double G[6][3] = {{1.0 / n0, 0.0, 0.0},      {1.0 / na, a / na, a * a / na}, {1.0 / na, -a / na, a * a / na},
+                            {1.0 / nb, b / nb, b * b / nb}, {1.0 / nb, -b / nb, b * b / nb}, {0.0, 0.0, 1.0}};
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % NcP);
+        const int ko = (int)(idx / NcP);                 // eight consecutive k
+        const int cog = n / (32 * NT), j = (n >> 5) % NT, l31 = n & 31, chunk = ko >> 1, hh = ko & 1;
+        float g[8][3][3];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = ko * 8 + i;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q2 = 0; q2 < 3; ++q2)
+                    g[i][p][q2] = (n < L.Nc && k < L.K)
+                                      ? src[(int64_t)L.tap_off0 + p * L.tap_off_sy + q2 * L.tap_off_sx + (int64_t)k * L.stride_k +
+                                            (int64_t)n * L.stride_n]
+                                      : 0.f;
+        }
+        for (int f = 0; f < 36; ++f) {
+            const int fa = f / 6, fb = f - fa * 6;
+            unsigned pl[3][4];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                float u2[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int q2 = 0; q2 < 3; ++q2) acc += G[fa][p] * G[fb][q2] * (double)g[2 * i2 + e][p][q2];
+                    u2[e] = (float)acc;
+                }
+                const unsigned hi = w4b_cvt_pk(u2[0], u2[1]);
+                const float r0 = u2[0] - __builtin_bit_cast(float, hi << 16), r1 = u2[1] - __builtin_bit_cast(float, hi & 0xffff0000u);
+                const unsigned mid = w4b_cvt_pk(r0, r1);
+                const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
+                pl[0][i2] = hi;
+                pl[1][i2] = mid;
+                pl[2][i2] = w4b_cvt_pk(s0, s1);
+            }
+            const int64_t grp = (((int64_t)cog * nchunks + chunk) * 36 + f) * NT + j;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wp[(grp * 3 + p) * 64 + hh * 32 + l31] = u32x4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+        }
+    }
+}
+
+extern "C" int adh_pack_weights_wino43_bf16x3(void* stream, const float* src, const adh_wlayout* L, void* wp) {
+    if (!src || !L || !wp || L->K < 1 || L->Nc < 1 || L->KHt != 3 || L->KWt != 3) return ADH_E_ARG;
+    const int KO = adh_round_up(L->K, 16) / 8;
+    const int NcP = adh_round_up(L->Nc, 32);
+    const int nt = NcP / 32, NT = nt % 3 == 0 ? 3 : (nt % 2 == 0 ? 2 : 1);
+    const int64_t total = (int64_t)KO * NcP;
+    hipLaunchKernelGGL(pack_weights_wino43_bf16x3_kernel, dim3(adh_min_i(adh_ceil_div(total, 128), 4096)), dim3(128), 0,
+                       (hipStream_t)stream, src, *L, KO, NcP, NT, reinterpret_cast<u32x4*>(wp));
     return adh_check_launch();
 }

@@ -29,6 +29,11 @@ USE_WINO43 = {"0": False, "1": True}.get(os.environ.get("ADH_WINO43", "1"), os.e
 # 2.75 / 2.50 / 2.52 ms on the 96 / 192 / 384-channel layers against 3.10 / 2.78 / 2.79 for the F(2x2,3x3)-domain kernel
 #  -- the default where it applies (Cin % 32 == 0, Cout % 96 == 0); ADH_WINO43_WGRAD=0 falls back
 USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "1") != "0"
+# Contraction arithmetic of the F(4x4,3x3) forward / data-gradient launches: "fp32" = v_mfma_f32_32x32x2_f32 (default, the
+# headline), "bf16x3" = v_mfma_f32_32x32x16_bf16 over exact three-plane bf16 splits of both operands (opt-in)
+CONTRACT = os.environ.get("ADH_CONTRACT", "fp32")
+if CONTRACT not in ("fp32", "bf16x3"):
+    raise ValueError(f"ADH_CONTRACT must be 'fp32' or 'bf16x3', got {CONTRACT!r}")
 W43_WGRAD_ROUNDS = int(os.environ.get("ADH_W43_WGRAD_ROUNDS", "4"))   # dev: rounds of workgroups the pixel splits may form
 USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"
 USE_FEWOUT = os.environ.get("ADH_FEWOUT", "1") != "0"               # conv_fewout.hip for the <= 4-output-channel 3x3 heads
@@ -441,7 +446,10 @@ class Engine:
                 if (w43 is True or w43 == ("dgrad" if gm["dstep"] == -1 else "fwd")) and \
                         H.value("adh_conv_wino43_supported", C.byref(d)):
                     wino = 43
-                    wp = self._packed("adh_pack_weights_wino43", w, Lw, 36 * (Kp // 4) * NcP * 4)
+                    if CONTRACT == "bf16x3":   # three bf16 planes of U: 6 bytes per weight and frequency
+                        wp = self._packed("adh_pack_weights_wino43_bf16x3", w, Lw, 36 * Kp * NcP * 3 // 2)
+                    else:
+                        wp = self._packed("adh_pack_weights_wino43", w, Lw, 36 * (Kp // 4) * NcP * 4)
                 else:
                     wino = bool(H.value("adh_conv_wino_supported", C.byref(d)))
                 if wino == 43:
@@ -553,10 +561,11 @@ class Engine:
             elif wino == "stem":
                 H.call("adh_conv_stem_forward", C.byref(d), work=work)
             elif wino == 43 and bnred is not None:
-                H.call("adh_conv_wino43_dgrad_bnred", C.byref(d), bnred[2].data_ptr(), work=work, work_exec=work * 0.25,
-                       family="adh_conv_wino43_forward")
+                H.call("adh_conv_wino43_dgrad_bnred" + ("_bf16x3" if CONTRACT == "bf16x3" else ""), C.byref(d), bnred[2].data_ptr(),
+                       work=work, work_exec=work * 0.25, family="adh_conv_wino43_forward")
             elif wino == 43:
-                H.call("adh_conv_wino43_forward", C.byref(d), work=work, work_exec=work * 0.25)
+                H.call("adh_conv_wino43_forward" + ("_bf16x3" if CONTRACT == "bf16x3" else ""), C.byref(d), work=work,
+                       work_exec=work * 0.25, family="adh_conv_wino43_forward")
             elif wino == 32:
                 H.call("adh_conv_wino32_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
             elif wino:

@@ -133,6 +133,17 @@ int adh_conv_wino43_forward(void* stream, const adh_conv_desc* d);
  * ResidualBlock (/root/reference models/dehazing/base_model.py:4-24,26-41). */
 int adh_conv_wino43_dgrad_bnred(void* stream, const adh_conv_desc* d, const float* bn_mean);
 int adh_pack_weights_wino43(void* stream, const float* src, const adh_wlayout* L, float* wp);
+/* Opt-in (round 4; host switch ADH_CONTRACT=bf16x3, the default stays the fp32 MFMA): the same two launches with the contraction
+ * on v_mfma_f32_32x32x16_bf16.  Both operands are split EXACTLY into three bf16 planes (x = hi + mid + lo, 3 x 8 significant
+ * bits; the transformed input inside the kernel, U at pack time) and the six significant cross terms are accumulated in fp32:
+ * the three dropped ones sit at 2^-24 of a product, measured error against fp64 0.7 - 0.9x the fp32 MFMA path's
+ * (profiles/r03_micro_bf16split.txt, profiles/r04_bf16x3_error.txt).  Same descriptor, same epilogue, same statistics rows as
+ * the fp32 entry points; d->wp from adh_pack_weights_wino43_bf16x3 (36 * Kp * NcP * 6 bytes, Kp = K rounded up to 16, NcP = Nc
+ * rounded up to 32; laid out per channel group as the launch picks it from NcP).  Replaces the same ATen conv2d calls
+ * (/root/reference models/dehazing/base_model.py:11-13,26-41). */
+int adh_conv_wino43_forward_bf16x3(void* stream, const adh_conv_desc* d);
+int adh_conv_wino43_dgrad_bnred_bf16x3(void* stream, const adh_conv_desc* d, const float* bn_mean);
+int adh_pack_weights_wino43_bf16x3(void* stream, const float* src, const adh_wlayout* L, void* wp);
 
 /* Weight gradient of the 3x3 s1 p1 convolutions with few channels (conv_wgrad_small.hip, MFMA 16x16x4: one tile = one tap
  * x 16 input channels x up to 16 output channels): channel strides (in, out) = (8, 16), (16, 16) or (48, 8), Cout <= 16 --

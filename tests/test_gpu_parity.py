@@ -367,7 +367,7 @@ def test_complex_fullwidth_vs_oracle_seeded(algo, monkeypatch):
 @pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 16, 16, 15, 23), (2, 32, 32, 7, 11), (1, 16, 48, 15, 23), (2, 96, 96, 16, 64),
                                            (1, 64, 192, 24, 40), (3, 32, 16, 8, 96), (1, 16, 16, 41, 66),
                                            (1, 32, 64, 24, 96), (1, 96, 96, 40, 160), (1, 48, 32, 40, 128)])   # interior regions
-@pytest.mark.parametrize("algo", ["f23", "f43"])
+@pytest.mark.parametrize("algo", ["f23", "f43", "f43-bf16x3"])
 def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, algo, monkeypatch):
     """Same layer through conv_wino_kernel (F(2x2,3x3)) / conv_wino43_kernel (F(4x4,3x3)) and the direct kernel: outputs
     and BatchNorm partial statistics agree to fp32 rounding, including ragged regions, channel tails (Co < 32) and the
@@ -379,7 +379,9 @@ def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, algo, monkeypatch):
     b = torch.randn(Co, generator=g).to(DEV)
     res = torch.randn(N, Hh, Ww, Co, generator=g).to(DEV)
     got = {}
-    monkeypatch.setattr(E, "USE_WINO43", {"f43": True, "f43-fwd": "fwd", "f43-dgrad": "dgrad"}.get(algo, False))
+    monkeypatch.setattr(E, "USE_WINO43", {"f43": True, "f43-bf16x3": True, "f43-fwd": "fwd", "f43-dgrad": "dgrad"}.get(algo, False))
+    # the bf16 x 3 contraction (opt-in) is held to the fp32 MFMA path's tolerance
+    monkeypatch.setattr(E, "CONTRACT", "bf16x3" if algo == "f43-bf16x3" else "fp32")
     tol = 4e-6 if algo == "f23" else 1.2e-5
     for wino in (False, True):
         monkeypatch.setattr(E, "USE_WINOGRAD", wino)
