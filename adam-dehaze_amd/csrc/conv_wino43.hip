@@ -55,23 +55,23 @@ static_assert(W4_TABOK + 4 * 640 <= W4_MF, "tables must end before the statistic
 #endif
 #define W4_PIECE_G0 2                              // ... the others one per contraction group from group W4_PIECE_G0 on
 
-// ---- bf16 x 3 contraction (round 4, opt-in: adh_conv_wino43_forward_bf16x3).  Same regions, same transform arithmetic, same
-// epilogue; the contraction runs on v_mfma_f32_32x32x16_bf16 with both operands split EXACTLY into three bf16 planes
-// (x = hi + mid + lo: 8 + 8 + 8 significant bits, each plane the round-to-nearest of what the previous ones left) and the six
-// significant cross terms hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi accumulated in fp32: 162 MFMAs of 32 cycles per chunk
-// and wave instead of 216 of 64 (tools/micro/bf16split.hip: 2.5x at 0.8x the fp32 MFMA's error against fp64; bf16ring.hip:
-// the weight stream keeps up at 1.12 - 1.38x the MFMA floor).  LDS map (bytes):
-//   [0, 73728)        T = pass 1's output [36][32 tiles][4 quads][16 B] (fp32), overwritten in place by pass 2 with the hi
-//                     and mid planes of the same four channels (8 B each; which half holds hi alternates with the tile so
-//                     that the 8-byte operand reads of 32 tiles hit 64 different banks)
-//   [73728, 110592)   lo plane [36][32 tiles][16 ch] bf16
-//   [110592, 151552)  raw halo (as the fp32 form)
-//   [151552, 156672)  slot tables, one entry per slot (the channel quad is added per lane: one VALU per piece is free
-//                     beside bf16 MFMAs)
-#define W4B_VLO_B 73728
-#define W4B_RAW_B 110592
-#define W4B_TAB_B 151552
-#define W4B_LDS_BYTES 156672
+// ---- bf16 x 3 contraction (round 4, opt-in: adh_conv_wino43_forward_bf16x3).  Same regions, same transform, same epilogue;
+// the contraction runs on v_mfma_f32_32x32x16_bf16 with both operands split EXACTLY into three bf16 planes (x = hi + mid + lo:
+// 8 + 8 + 8 significant bits, each plane the round-to-nearest of what the previous ones left) and the six significant cross
+// terms hi*hi, hi*mid, hi*lo, mid*hi, mid*mid, lo*hi accumulated in fp32: 162 MFMAs of 32 cycles per chunk and wave instead of
+// 216 of 64 (tools/micro/bf16split.hip: 2.5x at 0.8x the fp32 MFMA's error against fp64; bf16ring.hip: the weight stream keeps
+// up at 1.12 - 1.38x the MFMA floor).  U is split at pack time.  V stays fp32 in LDS, exactly as the fp32 form writes it; every
+// lane splits the eight values of its own A operand in registers, in the issue slots the bf16 MFMAs leave free (one wave per
+// SIMD: a VALU instruction behind an MFMA costs its issue cycles only while fewer than ~5 ride in a 32-cycle gap) -- a first
+// version that split in transform pass 2 and kept three planes in LDS paid 1.5 us per chunk for it (profiles/r04_bf16x3_*).
+// With V at 72 KB the raw halo is DOUBLE buffered: the pieces of chunk c + 1 are issued during pass 1 of chunk c and have landed
+// before the first weight wait of chunk c's contraction (vmcnt retires in order: a piece issued between two weight waits makes
+// the second one wait for HBM).  LDS map (bytes): [0, 73728) V | [73728, 155648) raw halo x 2 | [155648, 160768) slot tables,
+// one entry per slot (the channel quad is added per lane).
+#define W4B_RAW_B 73728
+#define W4B_RAWBUF_B 40960
+#define W4B_TAB_B 155648
+#define W4B_LDS_BYTES 160768
 static_assert(W4B_LDS_BYTES >= W4_LDS_BYTES && W4B_LDS_BYTES <= 160 * 1024, "LDS map of the bf16 x 3 variant");
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -126,10 +126,7 @@ __device__ __forceinline__ void w4_group(f32x16 (&acc)[9 * NT], const f32x4& a, 
 // does contraction group G carry a staging piece?  (dev build W4_DBG & 8: no staging inside the loop)
 constexpr int w4_piece(int G) { return (!(W4_DBG & 8) && G >= W4_PIECE_G0 && G < W4_PIECE_G0 + 10 - W4_P2) ? 1 : 0; }
 constexpr int w4_p2_pieces() { return (W4_DBG & 8) ? 0 : W4_P2; }
-#ifndef W4B_P2
-#define W4B_P2 10                                  // bf16 x 3 form: pieces issued during transform pass 2 (the rest in the contraction)
-#endif
-constexpr int w4b_p2_pieces() { return (W4_DBG & 8) ? 0 : W4B_P2; }
+
 struct W4Stage {                 // what a contraction group needs to issue one LDS-DMA piece of the NEXT chunk's raw halo
     __amdgpu_buffer_rsrc_t rsrc; // the image
     const int* tab_lane;         // this lane's entry of the offset table; piece u at [256 u]
@@ -245,38 +242,145 @@ __device__ __forceinline__ unsigned w4b_cvt_pk(float a, float b) {
     const f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-__device__ __forceinline__ f32x4 w4b_widen(unsigned p01, unsigned p23) {
-    return f32x4{__builtin_bit_cast(float, p01 << 16), __builtin_bit_cast(float, p01 & 0xffff0000u),
-                 __builtin_bit_cast(float, p23 << 16), __builtin_bit_cast(float, p23 & 0xffff0000u)};
+template <bool AGPR>
+__device__ __forceinline__ void w4b_mfma(f32x16& c, const u32x4& a, const u32x4& b) {
+    if constexpr (AGPR) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-// v = hi + mid + lo exactly (24 significant bits = 3 x 8: every subtraction below is exact)
-// (The residuals as v_dot2c_f32_bf16 -- x + (-1) * hi.lo + 0 * hi.hi, two instructions per pair instead of three -- were tried:
-// the instruction needs three wait states before another VALU instruction may read its result, hipcc's hazard recogniser does
-// not look into inline asm, its builtin does not select on this LLVM, and with the wait states the gain (1 %) is gone.)
-__device__ __forceinline__ void w4b_split(const f32x4& v, u32x2& hi, u32x2& mid, u32x2& lo, float m1) {
-    hi = u32x2{w4b_cvt_pk(v[0], v[1]), w4b_cvt_pk(v[2], v[3])};
-    const f32x4 r = adh_pksub(v, w4b_widen(hi[0], hi[1]), m1);
-    mid = u32x2{w4b_cvt_pk(r[0], r[1]), w4b_cvt_pk(r[2], r[3])};
-    const f32x4 r2 = adh_pksub(r, w4b_widen(mid[0], mid[1]), m1);
-    lo = u32x2{w4b_cvt_pk(r2[0], r2[1]), w4b_cvt_pk(r2[2], r2[3])};
+// the three planes of one (frequency, 32-channel tile) of U: [plane][64 lanes][16 B] = 3 KB contiguous (adh_pack_weights_wino43_bf16x3)
+__device__ __forceinline__ void w4b_load_b(u32x4 (&b)[3], unsigned voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[1]) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(b[2]) : "v"(voff), "s"(sbase) : "memory");
 }
-// pass 2 of the bf16 x 3 form: the six outputs of one frequency row, each split and stored as soon as it exists
-// (hi / mid: 8 bytes each into the thread's own 16-byte slot of T; lo: 8 bytes into the lo plane).  Pointers are in units of
-// 8 bytes; `stride` = 8-byte units between two frequencies of a row (256 for T, 128 for the lo plane).
-// Staging piece pb + i of the next chunk (i < np) rides behind the i-th output, one at a time: a burst backs the address unit up.
-// (No callable parameter: a __global__ template whose body passes a lambda into a function template loses its host stub in hipcc.)
-__device__ __forceinline__ void w4b_bt_split_store(f32x4 (&d)[6], u32x2* p_hi, u32x2* p_mid, u32x2* p_lo, const W4Neg& n, float m1,
-                                                   const W4Stage& st, const int (&vo)[6], int pb, int np) {
+template <int N>
+__device__ __forceinline__ void w4b_wait_b(u32x4 (&b)[3]) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N) : "memory");
+}
+// The A operand of the NEXT frequency in the making: s = the lane's eight fp32 values of V (channels 4h .. 4h+3 and 8+4h .. 8+4h+3
+// of its tile), turned into the residuals in place; h / m / l = the planes, two bf16 per register.  x = hi + mid + lo exactly
+// (24 significant bits = 3 x 8: every subtraction is exact).  Twenty steps: per pair p of values  A hi = cvt(s) | B s -= hi |
+// C mid = cvt(s) | D s -= mid | E lo = cvt(s), ordered A0 B0 .. A3 B3 C0 D0 .. C3 D3 E0 .. E3 (one to four VALU instructions each).
+struct W4BNext {
+    float s[8];
+    unsigned h[4], m[4], l[4];
+};
+// x -= the bf16 in the low / high half of pk.  One as a subtraction, the other as fma(., -1, .) with an opaque -1 (exact either
+// way): two subtractions side by side hipcc packs into one v_pk_add_f32, which costs far more than two scalar instructions in
+// the shadow of an MFMA (MI355X guide: +13 cycles each).
+#ifndef W4B_PKSUB
+#define W4B_PKSUB 1   // 1: two plain subtractions (hipcc packs them: v_pk_add_f32); 0: the sub + fma form (register pressure: see DESIGN 4.15)
+#endif
+__device__ __forceinline__ void w4b_sub_halves(float& x0, float& x1, unsigned pk, float m1) {
+    x0 -= __builtin_bit_cast(float, pk << 16);
+#if W4B_PKSUB
+    x1 -= __builtin_bit_cast(float, pk & 0xffff0000u);
+#else
+    x1 = __builtin_fmaf(__builtin_bit_cast(float, pk & 0xffff0000u), m1, x1);
+#endif
+}
+template <int STEP>
+__device__ __forceinline__ void w4b_step(W4BNext& n, float m1) {
+    if (W4_DBG & 16) return;   // dev build: no split (wrong results): what the fillers cost the contraction
+    constexpr int p = STEP < 16 ? (STEP & 7) >> 1 : STEP - 16;
+    constexpr int kind = STEP < 16 ? (STEP & 1) + 2 * (STEP >> 3) : 4;
+    if constexpr (kind == 0) n.h[p] = w4b_cvt_pk(n.s[2 * p], n.s[2 * p + 1]);
+    if constexpr (kind == 1) w4b_sub_halves(n.s[2 * p], n.s[2 * p + 1], n.h[p], m1);
+    if constexpr (kind == 2) n.m[p] = w4b_cvt_pk(n.s[2 * p], n.s[2 * p + 1]);
+    if constexpr (kind == 3) w4b_sub_halves(n.s[2 * p], n.s[2 * p + 1], n.m[p], m1);
+    if constexpr (kind == 4) n.l[p] = w4b_cvt_pk(n.s[2 * p], n.s[2 * p + 1]);
+}
+template <int S0, int S1>
+__device__ __forceinline__ void w4b_steps(W4BNext& n, float m1) {
+    if constexpr (S0 < S1) {
+        w4b_step<S0>(n, m1);
+        w4b_steps<S0 + 1, S1>(n, m1);
+    }
+}
+// the gap behind MFMA M (1 .. NM = 6 NT) of a frequency in which step S runs: from gap 3 on (the values requested in gap NM - 1 of
+// the frequency before have landed by then), the last one in gap NM - 1
+template <int NM>
+constexpr int w4b_gap_of(int S) { return 3 + S * (NM - 3) / 20; }
+template <int NM, int M, int S = 0>
+constexpr int w4b_first_step() {   // first step whose gap is >= M
+    if constexpr (S >= 20) return 20;
+    else if constexpr (w4b_gap_of<NM>(S) >= M) return S;
+    else return w4b_first_step<NM, M, S + 1>();
+}
+__device__ __forceinline__ void w4b_load_s(W4BNext& n, const float* v0, const float* v1) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(v0), b = *reinterpret_cast<const f32x4*>(v1);
+    n.s[0] = a[0]; n.s[1] = a[1]; n.s[2] = a[2]; n.s[3] = a[3];
+    n.s[4] = b[0]; n.s[5] = b[1]; n.s[6] = b[2]; n.s[7] = b[3];
+}
+// what rides behind MFMA M of frequency FI: the steps of its gap towards frequency FI + 1's planes and, behind the last step, the
+// request for frequency FI + 2's values; pinned there (the scheduler would otherwise bunch the VALU work of a frequency together,
+// and the MFMA pipe idles behind a bunch)
+template <int NT, int FI, int M>
+__device__ __forceinline__ void w4b_gap(W4BNext& n, const float* vlane, const float* vlane1, float m1) {
+    constexpr int NM = 6 * NT;
+    if constexpr (FI + 1 < 9) {
+        w4b_steps<w4b_first_step<NM, M>(), w4b_first_step<NM, M + 1>()>(n, m1);
+        if constexpr (M == NM - 1 && FI + 2 < 9) w4b_load_s(n, vlane + (FI + 2) * (W4_TILES * W4_KC), vlane1 + (FI + 2) * (W4_TILES * W4_KC));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+// groups G .. 9 NT - 1 of one chunk: group = (frequency G / NT, channel tile G % NT) = three weight loads two groups ahead
+// (ring of three) and six MFMAs on one accumulator tile (back to back on one accumulator is full rate for this instruction), in
+// the order hi*hi, hi*mid, hi*lo | mid*hi, mid*mid | lo*hi.  NOTHING is requested across the chunk boundary.  (Tried, as the fp32
+// form does it: the last two groups requesting the next chunk's groups 0 and 1.  hipcc resolved the loop-carried ring with register
+// COPIES -- v_mov of a register whose load was still in flight, placed right behind the load, in front of any wait the source can
+// express -- and interior regions, where nothing slow sits between the last group and the back edge, computed garbage.  It bought
+// nothing either: 1.881 / 1.428 / 1.374 ms against 1.879 / 1.443 / 1.380, the staging pieces gate group 2 instead of group 0.
+// tests/test_host_cpu.py now walks both forms' ISA for reads of a register between its asm load and the wait that covers it.)
+#ifndef W4B_P1
+#define W4B_P1 5      // dev: staging pieces issued in pass 1 (the rest in pass 2)
+#endif
+template <int NT, int G>
+__device__ __forceinline__ void w4b_groups(f32x16 (&acc)[9 * NT], u32x4 (&a)[3], W4BNext& n, u32x4 (&bv)[3][3], const float* vlane,
+                                           const float* vlane1, unsigned b_voff, const char* b_chunk, float m1) {
+    if constexpr (G < 9 * NT) {
+        constexpr int FI = G / NT, J = G % NT, G2 = G + 2;
+        if constexpr (G2 < 9 * NT) w4b_load_b(bv[G2 % 3], b_voff, b_chunk + G2 * 3072);
+        constexpr int newer = 3 * (9 * NT - 1 - G < 2 ? 9 * NT - 1 - G : 2);
+        constexpr bool agpr = w4_in_agpr<NT, FI, J>();
+        u32x4(&b)[3] = bv[G % 3];
+        w4b_wait_b<newer>(b);
+        w4b_mfma<agpr>(acc[G], a[0], b[0]);
+        w4b_gap<NT, FI, 6 * J + 1>(n, vlane, vlane1, m1);
+        w4b_mfma<agpr>(acc[G], a[0], b[1]);
+        w4b_gap<NT, FI, 6 * J + 2>(n, vlane, vlane1, m1);
+        w4b_mfma<agpr>(acc[G], a[0], b[2]);
+        w4b_gap<NT, FI, 6 * J + 3>(n, vlane, vlane1, m1);
+        w4b_mfma<agpr>(acc[G], a[1], b[0]);
+        w4b_gap<NT, FI, 6 * J + 4>(n, vlane, vlane1, m1);
+        w4b_mfma<agpr>(acc[G], a[1], b[1]);
+        w4b_gap<NT, FI, 6 * J + 5>(n, vlane, vlane1, m1);
+        w4b_mfma<agpr>(acc[G], a[2], b[0]);
+        if constexpr (J == NT - 1 && FI + 1 < 9) {
+            // hand-over: the planes of frequency FI + 1 (written by VALU instructions at least one MFMA ago; the asm holds the two wait
+            // states an MFMA operand needs behind a VALU write in case a register copy lands here: hipcc's hazard recogniser does not
+            // look into the MFMA statements)
+            a[0] = u32x4{n.h[0], n.h[1], n.h[2], n.h[3]};
+            a[1] = u32x4{n.m[0], n.m[1], n.m[2], n.m[3]};
+            a[2] = u32x4{n.l[0], n.l[1], n.l[2], n.l[3]};
+            asm volatile("s_nop 1" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
+        } else {
+            w4b_gap<NT, FI, 6 * J + 6>(n, vlane, vlane1, m1);
+        }
+        w4b_groups<NT, G + 1>(acc, a, n, bv, vlane, vlane1, b_voff, b_chunk, m1);
+    }
+}
+// 1-D input transform as w4_bt_store, with staging piece pb + i of the next chunk riding behind the i-th store (i < np), one at
+// a time: a burst backs the address unit up.  (No callable parameter: a __global__ template whose body passes a lambda into a
+// function template loses its host stub in hipcc.)
+__device__ __forceinline__ void w4b_bt_store_staging(f32x4 (&d)[6], float* dst, int stride, const W4Neg& n, const W4Stage& st,
+                                                     const int (&vo)[4], int lds_buf, int pb, int np) {
     int nput = 0;
-    auto put = [&](int b, const f32x4& v) {
-        u32x2 hi, mid, lo;
-        w4b_split(v, hi, mid, lo, m1);
-        p_hi[b * 256] = hi;
-        p_mid[b * 256] = mid;
-        p_lo[b * 128] = lo;
+    auto put = [&](int a, const f32x4& v) {
+        *reinterpret_cast<f32x4*>(dst + a * stride) = v;
         if (nput < np) {
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(st.lds) + st.lds_wave + (pb + nput) * 4096), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(st.lds) + lds_buf + (pb + nput) * 4096), 16,
                                                      vo[nput], st.cb, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -293,109 +397,6 @@ __device__ __forceinline__ void w4b_bt_split_store(f32x4 (&d)[6], u32x2* p_hi, u
     put(3, W4_B * s + r);
     put(4, n.b * s + r);
 }
-template <bool AGPR>
-__device__ __forceinline__ void w4b_mfma(f32x16& c, const u32x4& a, const u32x4& b) {
-    if constexpr (AGPR) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-// the three planes of one (frequency, 32-channel tile) of U: [plane][64 lanes][16 B] = 3 KB contiguous (adh_pack_weights_wino43_bf16x3)
-__device__ __forceinline__ void w4b_load_b(u32x4 (&b)[3], unsigned voff, const char* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(voff), "s"(sbase) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[1]) : "v"(voff), "s"(sbase) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(b[2]) : "v"(voff), "s"(sbase) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void w4b_wait_b(u32x4 (&b)[3]) {
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N) : "memory");
-}
-// staging pieces (10 per wave and chunk) carried by contraction group G: one behind the first MFMA of groups 2 .. 11, or,
-// with nine groups per chunk (NT = 1), two in groups 2 .. 6
-template <int NT>
-constexpr int w4b_pieces(int G) {
-    if (W4_DBG & 8) return 0;
-    constexpr int left = 10 - W4B_P2;
-    if (NT == 1) return (G >= 2 && 2 * (G - 2) < left) ? 2 : 0;
-    return (G >= 2 && G - 2 < left) ? 1 : 0;
-}
-template <int NT>
-constexpr int w4b_piece0(int G) { return W4B_P2 + (NT == 1 ? 2 * (G - 2) : G - 2); }
-struct W4BLane {            // this lane's A operand addresses (frequency 0 of its wave)
-    const u32x2* hi0;       // hi plane, channels 8h .. 8h+3 (8-byte units; the other three are this ^ 2, ^ 1, ^ 3)
-    const u32x2* hi1;
-    const u32x2* mid0;
-    const u32x2* mid1;
-    const u32x4* lo;        // lo plane, channels 8h .. 8h+7
-    int quad16;             // (lane & 3) * 16: the channel quad a lane stages
-};
-template <int FI, int P>   // plane P (0 hi, 1 mid, 2 lo) of the wave's frequency FI
-__device__ __forceinline__ void w4b_load_a(u32x4& a, const W4BLane& la) {
-    if constexpr (P == 2) {
-        a = la.lo[FI * 64];
-    } else {
-        const u32x2 q0 = (P ? la.mid0 : la.hi0)[FI * 256], q1 = (P ? la.mid1 : la.hi1)[FI * 256];
-        a = u32x4{q0[0], q0[1], q1[0], q1[1]};
-    }
-}
-// groups G .. 9 NT - 1 of one chunk: group = (frequency G / NT, channel tile G % NT) = three weight loads two groups ahead
-// (ring of three) and six MFMAs on one accumulator tile (back to back on one accumulator is full rate for this instruction), in
-// the order lo*hi | mid*mid, mid*hi | hi*lo, hi*mid, hi*hi.  The V planes are SINGLE buffered (12 registers: next to 27
-// accumulator tiles and the weight ring there is no room for a second set): in the last group of a frequency each plane of
-// the next frequency is requested right behind the last MFMA that reads the old one and is needed four or five MFMAs later.
-template <int NT, int G>
-__device__ __forceinline__ void w4b_groups(f32x16 (&acc)[9 * NT], u32x4 (&a)[3], u32x4 (&bv)[3][3], const W4BLane& la, unsigned b_voff,
-                                           const char* b_chunk, const W4Stage& st) {
-    if constexpr (G < 9 * NT) {
-        constexpr int FI = G / NT, J = G % NT, G2 = G + 2;
-        // (nothing is requested across the chunk boundary: registers an asm load is still filling must not be live through
-        // the transform, where hipcc is free to spill them -- it would store them before they have landed)
-        if constexpr (G2 < 9 * NT) w4b_load_b(bv[G2 % 3], b_voff, b_chunk + G2 * 3072);
-        constexpr int newer = 3 * (9 * NT - 1 - G < 2 ? 9 * NT - 1 - G : 2);
-        constexpr bool nextf = J == NT - 1 && FI + 1 < 9;
-        constexpr int np = w4b_pieces<NT>(G);
-        constexpr bool agpr = w4_in_agpr<NT, FI, J>();
-        u32x4(&b)[3] = bv[G % 3];
-        int vo[np > 0 ? np : 1];
-        if constexpr (np > 0) {   // the pieces' table entries: requested before the wait so that the round trip is over behind the first MFMA
-#pragma unroll
-            for (int e = 0; e < np; ++e) vo[e] = st.tab_lane[64 * (w4b_piece0<NT>(G) + e)];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // newer than this group's weights: the weights of the next two groups and the pieces of the previous two
-        w4b_wait_b<newer + w4b_pieces<NT>(G - 2) + w4b_pieces<NT>(G - 1)>(b);
-        w4b_mfma<agpr>(acc[G], a[2], b[0]);
-        if constexpr (nextf) {
-            __builtin_amdgcn_sched_barrier(0);
-            w4b_load_a<FI + 1, 2>(a[2], la);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (np > 0) {
-#pragma unroll
-            for (int e = 0; e < np; ++e) vo[e] += la.quad16;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < np; ++e)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(st.lds) + st.lds_wave + (w4b_piece0<NT>(G) + e) * 4096),
-                                                         16, vo[e], st.cb, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        w4b_mfma<agpr>(acc[G], a[1], b[1]);
-        w4b_mfma<agpr>(acc[G], a[1], b[0]);
-        if constexpr (nextf) {
-            __builtin_amdgcn_sched_barrier(0);
-            w4b_load_a<FI + 1, 1>(a[1], la);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        w4b_mfma<agpr>(acc[G], a[0], b[2]);
-        w4b_mfma<agpr>(acc[G], a[0], b[1]);
-        w4b_mfma<agpr>(acc[G], a[0], b[0]);
-        if constexpr (nextf) {
-            __builtin_amdgcn_sched_barrier(0);
-            w4b_load_a<FI + 1, 0>(a[0], la);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        w4b_groups<NT, G + 1>(acc, a, bv, la, b_voff, b_chunk, st);
-    }
-}
 
 template <int NT, bool BNRED = false, bool BF3 = false>
 __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc d, const Wino43Geom g) {
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     constexpr int RAW0 = BF3 ? W4B_RAW_B / 4 : W4_VF;                   // float offset of the raw halo
     float* const rawbase = lds + RAW0;
     // fp32 form: [640][4] source byte offset of (slot s, channel quad q) (clamped) and [640][4] slot-inside-image flags;
-    // bf16 x 3 form: one entry per slot, [640] offsets then [640] flags
+    // bf16 x 3 form: one entry per slot, [640] offsets then [640] flags, and two raw buffers (chunk c reads buffer c & 1)
     int* const tab_off = reinterpret_cast<int*>(lds + (BF3 ? W4B_TAB_B / 4 : W4_TAB));
     int* const tab_ok = BF3 ? tab_off + 640 : reinterpret_cast<int*>(lds + W4_TABOK);
     float* const red = lds + W4_RED;
@@ -468,52 +469,88 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     st.lds_wave = __builtin_amdgcn_readfirstlane((RAW0 + wave * 256) * 4);
     st.cb = 0;
     constexpr int TABU = BF3 ? 64 : 256;          // table entries between two pieces of a wave
-    const int quad16 = (lane & 3) * 16;
+    const int quad16_o = (lane & 3) * 16;
     auto stage_first = [&]() {   // chunk 0 (prologue); the later chunks arrive piece by piece inside the contraction
         int vo[10];   // all table reads first: one LDS round trip instead of ten
 #pragma unroll
-        for (int u = 0; u < 10; ++u) vo[u] = st.tab_lane[TABU * u] + (BF3 ? quad16 : 0);
+        for (int u = 0; u < 10; ++u) vo[u] = st.tab_lane[TABU * u] + (BF3 ? quad16_o : 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 10; ++u)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + u * 4096), 16,
                                                      vo[u], 0, 0, 0);
     };
-    auto fix_raw = [&]() {
+    // bf16 x 3 form: next to 27 accumulator tiles, the weight ring and the planes in the making, the contraction has fewer than ten
+    // registers to spare: nothing a thread needs only OUTSIDE the contraction may stay live across it.  Such per-thread constants are
+    // rebuilt from v_mbcnt where they are used (the asm keeps hipcc from hoisting the rebuild back out of the chunk loop).
+    auto lane_rebuilt = [&]() {
+        int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    auto fix_raw = [&](int buf = 0) {   // (bf16 x 3 form: buf = the raw buffer just staged)
         if (interior) return;
-        float* raw = rawbase + wave * 256 + lane * 4;
+        const int ln = BF3 ? lane_rebuilt() : lane;
+        const int* const tabl = BF3 ? tab_off + 16 * wave + (ln >> 2) : st.tab_lane;
+        float* raw = rawbase + buf * (W4B_RAWBUF_B / 4) + wave * 256 + ln * 4;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 10; ++u)
-            if (!st.tab_lane[(BF3 ? 640 : 4 * 640) + TABU * u]) *reinterpret_cast<f32x4*>(raw + u * 1024) = z;
+            if (!tabl[(BF3 ? 640 : 4 * 640) + TABU * u]) *reinterpret_cast<f32x4*>(raw + u * 1024) = z;
     };
 
     // ------------------------------------------------------------------ input transform (two 1-D passes through LDS)
     // thread = (tile, channel quad); pass 1 item k: patch column c = 2k + (tid >> 7); pass 2 item k: frequency row a = ...
     const int tile_t = (tid >> 2) & 31, trow = tile_t >> 3, tcol = tile_t & 7;
     const int csel = wave >> 1;                                                 // 0 / 1 (wave-uniform)
-    // swizzled quad slot inside V[f][tile] (bf16 x 3 form: the slot permutation that makes the 8-byte operand reads conflict-free)
-    const int vslot_t = tile_t * 16 + ((cq_l ^ ((BF3 ? tile_t >> 2 : tile_t >> 1) & 3)) * 4);
+    // swizzled quad slot inside V[f][tile]
+    const int vslot_o = tile_t * 16 + ((cq_l ^ ((tile_t >> 1) & 3)) * 4);
     // patch pixel (row i, column c) of this thread's tile sits in raw row 4*trow + i, plane c & 3, index tcol + (c >> 2);
     // slot offset of column c = 2k + csel inside a row: {0, 18, 1} (csel 0: planes 0, 2, 0) / {9, 26, 10} (csel 1)
     // -> two lane pointers (k = 0 and, one slot further, k = 2; k = 1), the patch row is an instruction immediate
     const int rbase_t = ((4 * trow) * W4_ROWSLOTS + tcol) * 16 + cq_l * 4;
-    const int raw_k0 = (RAW0 + rbase_t) / 4 + (csel ? 9 : 0) * 4;      // float4 indices into lds[] (an opaque *pointer* would lose the LDS
-    const int raw_k1 = (RAW0 + rbase_t) / 4 + (csel ? 26 : 18) * 4;    // address space: flat loads; an opaque float index the alignment: b32 reads)
+    const int raw_k0_o = (RAW0 + rbase_t) / 4 + (csel ? 9 : 0) * 4;      // float4 indices into lds[] (an opaque *pointer* would lose the LDS
+    const int raw_k1_o = (RAW0 + rbase_t) / 4 + (csel ? 26 : 18) * 4;    // address space: flat loads; an opaque float index the alignment: b32 reads)
     const W4Neg negc = w4_neg_constants();
-    const float m1t = adh_opaque(-1.f);
-    constexpr int p2n = BF3 ? w4b_p2_pieces() : w4_p2_pieces();   // pieces of the next chunk's halo issued during pass 2
-    auto transform = [&]() {
+    constexpr int p2n = BF3 ? 0 : w4_p2_pieces();   // pieces of the next chunk's halo issued during pass 2 (fp32 form, dev option)
+    auto transform = [&](int cbuf) {   // cbuf (bf16 x 3 form) = c & 1: the raw buffer this chunk reads; the other one is staged
+        int vslot_t = vslot_o, raw_k0 = raw_k0_o, raw_k1 = raw_k1_o, quad16 = quad16_o;
+        const int* tabl = st.tab_lane;
+        if constexpr (BF3) {   // (see lane_rebuilt)
+            const int ln = lane_rebuilt();
+            const int tl = ((wave & 1) << 4) | (ln >> 2), cq = ln & 3;
+            vslot_t = tl * 16 + ((cq ^ ((tl >> 1) & 3)) * 4);
+            const int rb = ((4 * (tl >> 3)) * W4_ROWSLOTS + (tl & 7)) * 16 + cq * 4;
+            raw_k0 = (RAW0 + rb) / 4 + (csel ? 9 : 0) * 4;
+            raw_k1 = (RAW0 + rb) / 4 + (csel ? 26 : 18) * 4;
+            quad16 = cq * 16;
+            tabl = tab_off + 16 * wave + (ln >> 2);
+        }
         // pass 1: T[a][c] = sum_i B^T[a][i] d[i][c] for this thread's three columns c = csel, 2 + csel, 4 + csel
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int c = 2 * k + csel;
             f32x4 dd[6];
             int rp = k == 1 ? raw_k1 : raw_k0 + (k == 2 ? 4 : 0);
+            if constexpr (BF3) rp += cbuf * (W4B_RAWBUF_B / 16);
             asm volatile("" : "+v"(rp));   // (keeps the six row addresses from being hoisted out of the chunk loop into six registers)
+            // bf16 x 3 form: the ten pieces of the NEXT chunk's halo ride behind the stores of the two passes, 2 + 2 + 1 each, into the
+            // other raw buffer (all ten in this pass queue up in the address unit, which serves the four waves' pieces one by one)
+            int vo[4];
+            const int pb = W4B_P1 == 5 ? 2 * k : (k == 0 ? 0 : (k == 1 ? 4 : 7)),
+                      pn = (W4_DBG & 8) ? 0 : (W4B_P1 == 5 ? (k == 2 ? 1 : 2) : (k == 0 ? 4 : 3));
+            if constexpr (BF3) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < pn) vo[e] = tabl[TABU * (pb + e)] + quad16;
+            }
 #pragma unroll
             for (int i = 0; i < 6; ++i) dd[i] = reinterpret_cast<const f32x4*>(lds)[rp + i * (W4_ROWSLOTS * 4)];
-            w4_bt_store(dd, lds + c * (W4_TILES * W4_KC) + vslot_t, 6 * W4_TILES * W4_KC, negc);
+            if constexpr (BF3)
+                w4b_bt_store_staging(dd, lds + c * (W4_TILES * W4_KC) + vslot_t, 6 * W4_TILES * W4_KC, negc, st, vo,
+                                     st.lds_wave + (cbuf ^ 1) * W4B_RAWBUF_B, pb, pn);
+            else
+                w4_bt_store(dd, lds + c * (W4_TILES * W4_KC) + vslot_t, 6 * W4_TILES * W4_KC, negc);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -523,34 +560,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         for (int k = 0; k < 3; ++k) {
             const int a = 2 * k + csel;
             f32x4 tt[6];
-            // pieces of the next chunk's halo (the raw buffer's last reader was pass 1): table entries first.  fp32 form: pieces
-            // k, k + 3, .. behind the row; bf16 x 3 form: as early as possible (they must have landed before the first weight wait
-            // of the contraction, vmcnt being in order), one behind each of the first outputs: six in row 0, four in row 1
-            constexpr int PE = 6;   // (entries used: 6 / 4.  One type for both forms: a discarded `if constexpr` branch inside this lambda is still checked on hipcc's host pass, and a mismatch there silently drops the kernel's host stub)
-            const int pb = BF3 ? (k == 0 ? 0 : (k == 1 ? 6 : 10)) : k, pstep = BF3 ? 1 : 3;
-            int vo[PE];
+            // (fp32 form, dev option W4_P2) pieces k, k + 3, .. of the next chunk's halo (the raw buffer's last reader was pass 1): table entries first
+            int vo[4];
+            const int pb = 5 + 2 * k, pn = (W4_DBG & 8) || W4B_P1 != 5 ? 0 : (k == 2 ? 1 : 2);   // bf16 x 3 form: pieces 5 .. 9
 #pragma unroll
-            for (int e = 0; e < (BF3 ? 6 : 4); ++e)
-                if (pb + pstep * e < p2n) vo[e] = st.tab_lane[TABU * (pb + pstep * e)] + (BF3 ? quad16 : 0);
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (BF3) {
+                    if (e < pn) vo[e] = tabl[TABU * (pb + e)] + quad16;
+                } else {
+                    if (k + 3 * e < p2n) vo[e] = tabl[TABU * (k + 3 * e)];
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 6; ++c) tt[c] = *reinterpret_cast<const f32x4*>(lds + (a * 6 + c) * (W4_TILES * W4_KC) + vslot_t);
-            if constexpr (BF3) {
-                // the three planes of the thread's four channels: hi and mid share its slot (hi in the half `hsub` of the tile
-                // says), lo goes to the lo plane [f][tile][(channel half ^ tile bit 3)][quad & 1]
-                const int hsub = ((tile_t >> 1) ^ (tile_t >> 4)) & 1;
-                u32x2* const l8 = reinterpret_cast<u32x2*>(lds);
-                const int slot8 = (a * 6) * 256 + vslot_t / 2;
-                const int lo8 = W4B_VLO_B / 8 + (a * 6) * 128 + tile_t * 4 + (((cq_l >> 1) ^ ((tile_t >> 3) & 1)) * 2) + (cq_l & 1);
-                w4b_bt_split_store(tt, l8 + slot8 + hsub, l8 + slot8 + (hsub ^ 1), l8 + lo8, negc, m1t, st, vo, pb,
-                                   pb >= p2n ? 0 : (p2n - pb < PE ? p2n - pb : PE));
-            } else {
+            if constexpr (BF3)
+                w4b_bt_store_staging(tt, lds + (a * 6) * (W4_TILES * W4_KC) + vslot_t, W4_TILES * W4_KC, negc, st, vo,
+                                     st.lds_wave + (cbuf ^ 1) * W4B_RAWBUF_B, pb, pn);
+            else
                 w4_bt_store(tt, lds + (a * 6) * (W4_TILES * W4_KC) + vslot_t, W4_TILES * W4_KC, negc);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (k + 3 * e < p2n)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + (k + 3 * e) * 4096),
-                                                                 16, vo[e], st.cb, 0, 0);
-            }
+            for (int e = 0; e < 4; ++e)
+                if (k + 3 * e < p2n)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + (k + 3 * e) * 4096),
+                                                             16, vo[e], st.cb, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -566,22 +598,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const int64_t b_fstride = (int64_t)g.KQtot * d.NcP * 4;   // floats per frequency
     const int b_kq = d.NcP * 4;                                // floats per channel quad
 
-    // bf16 x 3 form.  A: the lane's tile l31, channels 8h .. 8h+7 of each plane: hi / mid as two 8-byte reads (quads 2h, 2h+1 of the
-    // tile's 64-byte block, slot permutation (tile >> 2) & 3, hi in half ((tile >> 1) ^ (tile >> 4)) & 1 of a slot), lo as one
-    // 16-byte read.  B: adh_pack_weights_wino43_bf16x3's [cog][chunk][36 f][NT][3 planes][64 lanes][16 B]: the 9 NT groups of a wave
-    // and chunk are 27 NT KB contiguous, lane offset 16 * lane
-    W4BLane la;
-    {
-        const int s3 = (l31 >> 2) & 3, hs = ((l31 >> 1) ^ (l31 >> 4)) & 1;
-        const int base8 = (wave * 9) * 256 + l31 * 8 + (((2 * h) ^ s3) * 2) + hs;       // 8-byte units
-        const u32x2* const l8 = reinterpret_cast<const u32x2*>(lds);
-        la.hi0 = l8 + base8;
-        la.hi1 = l8 + (base8 ^ 2);
-        la.mid0 = l8 + (base8 ^ 1);
-        la.mid1 = l8 + (base8 ^ 3);
-        la.lo = reinterpret_cast<const u32x4*>(lds) + W4B_VLO_B / 16 + (wave * 9) * 64 + l31 * 2 + (h ^ ((l31 >> 3) & 1));
-        la.quad16 = quad16;
-    }
+    // bf16 x 3 form.  A: the same two 16-byte reads per frequency (the lane's tile, channel quads h and 2 + h), split in registers.
+    // B: adh_pack_weights_wino43_bf16x3's [cog][chunk][36 f][NT][3 planes][64 lanes][16 B]: the 9 NT groups of a wave and chunk
+    // are 27 NT KB contiguous, lane offset 16 * lane
     const unsigned b3_voff = (unsigned)lane * 16u;
     const size_t b3_cstride = (size_t)36 * NT * 3072;                                   // bytes of U per chunk and channel group
     const char* const b3_wave = reinterpret_cast<const char*>(d.wp) + ((size_t)cg * g.nchunks * 36 + (size_t)wave * 9) * (NT * 3072);
@@ -589,6 +608,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     f32x16 acc[9 * NT];
     f32x4 av[2], bv[3][NT];
     u32x4 av3[3], bv3[3][3];
+    W4BNext nx;
+    const float m1s = adh_opaque(-1.f);
 
     // ------------------------------------------------------------------ prologue
     __syncthreads();   // slot tables
@@ -615,10 +636,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         st.cb = cn * (W4_KC * 4);
         if (c == 1) W4_STAMP(8);
         if (c == 1) W4_STAMP(9);
-        if (!(W4_DBG & 1)) transform();
+        if (!(W4_DBG & 1)) transform(c & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (c == 1) W4_STAMP(10);
-        if constexpr (BF3) {   // the weights of groups 0 and 1: requested here, behind the transform (see w4b_groups)
+        if constexpr (BF3) {   // the weights of groups 0 and 1: on their way during the barrier and the first frequency's split
             if (!(W4_DBG & 2)) {
                 w4b_load_b(bv3[0], b3_voff, b3_wave + c * b3_cstride);
                 w4b_load_b(bv3[1], b3_voff, b3_wave + c * b3_cstride + 3072);
@@ -631,10 +652,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         // meanwhile; the weight waits of the later groups retire the pieces in order
         if constexpr (BF3) {
             if (!(W4_DBG & 2)) {
-                w4b_load_a<0, 0>(av3[0], la);
-                w4b_load_a<0, 1>(av3[1], la);
-                w4b_load_a<0, 2>(av3[2], la);
-                w4b_groups<NT, 0>(acc, av3, bv3, la, b3_voff, b3_wave + c * b3_cstride, st);
+                // the planes of the wave's first frequency, split while the first weights are on their way; then the values of the second
+                w4b_load_s(nx, vlane, vlane1);
+                w4b_steps<0, 20>(nx, m1s);
+                av3[0] = u32x4{nx.h[0], nx.h[1], nx.h[2], nx.h[3]};
+                av3[1] = u32x4{nx.m[0], nx.m[1], nx.m[2], nx.m[3]};
+                av3[2] = u32x4{nx.l[0], nx.l[1], nx.l[2], nx.l[3]};
+                asm volatile("s_nop 1" : "+v"(av3[0]), "+v"(av3[1]), "+v"(av3[2]));
+                w4b_load_s(nx, vlane + W4_TILES * W4_KC, vlane1 + W4_TILES * W4_KC);
+                __builtin_amdgcn_sched_barrier(0);
+                w4b_groups<NT, 0>(acc, av3, nx, bv3, vlane, vlane1, b3_voff, b3_wave + c * b3_cstride, m1s);
             }
         } else if (!(W4_DBG & 2)) {
             const float* b_chunk = b_wave + (int64_t)(c * 4) * b_kq;
@@ -654,7 +681,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             w4_chunk<NT, 2>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, 2 * b_kq, st);
         }
         if (c == 1) W4_STAMP(12);
-        fix_raw();
+        fix_raw(BF3 ? ((c + 1) & 1) : 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (c == 1) W4_STAMP(13);
@@ -1013,8 +1040,8 @@ extern "C" int adh_pack_weights_wino43(void* stream, const float* src, const adh
 }
 
 // The same U = G g G^T (computed in double, rounded to fp32 exactly as above), split into three bf16 planes and laid out for
-// conv_wino43_kernel<NT, *, true>: [channel group of 32 NT][chunk of 16 k][36 f][NT tiles][3 planes][half h][32 n][8 k] bf16, NT as
-// the launch picks it from NcP.  wp: 36 * Kp * NcP * 6 bytes (Kp = K rounded up to 16, NcP = Nc rounded up to 32).
+// conv_wino43_kernel<NT, *, true>: [channel group of 32 NT][chunk of 16 k][36 f][NT tiles][3 planes][half h][32 n][8 k] bf16 (the
+// eight k of half h: channels 4h .. 4h+3 and 8+4h .. 8+4h+3 of the chunk), NT as the launch picks it from NcP.  wp: 36 * Kp * NcP * 6 bytes (Kp = K rounded up to 16, NcP = Nc rounded up to 32).
 __global__ void pack_weights_wino43_bf16x3_kernel(const float* __restrict__ src, const adh_wlayout L, int KO, int NcP, int NT,
                                                   u32x4* __restrict__ wp) {
     const int64_t total = (int64_t)KO * NcP;
@@ -1026,12 +1053,13 @@ __global__ void pack_weights_wino43_bf16x3_kernel(const float* __restrict__ src,
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(idx % NcP);
-        const int ko = (int)(idx / NcP);                 // eight consecutive k
+        const int ko = (int)(idx / NcP);                 // the eight k of lane half hh of chunk `chunk`
         const int cog = n / (32 * NT), j = (n >> 5) % NT, l31 = n & 31, chunk = ko >> 1, hh = ko & 1;
         float g[8][3][3];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int k = ko * 8 + i;
+            // k-slot i of lane half hh = the kernel's A operand: channel quads hh and 2 + hh of the chunk
+            const int k = chunk * 16 + (i < 4 ? 4 * hh + i : 8 + 4 * hh + (i - 4));
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
