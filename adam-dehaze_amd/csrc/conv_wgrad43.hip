@@ -36,10 +36,13 @@
 
 #ifndef G4_DBG
 #define G4_DBG 0   // dev builds: 1 = skip the transform, 4 = skip the contraction, 8 = stage only the first strip,
-                   // 16 = do not wait for the pieces (wrong results), 32 = pieces in one burst before the contraction,
-                   // 64 = every strip stages the same pixels, 128 / 256 = degenerate per-lane patterns (issue-cost probes),
-                   // 512 = only lane 0 of every piece is active (the instruction issues, 16 bytes move)
+                   // 16 = do not wait for the pieces (wrong results), 32 = pieces in one burst before the contraction.
+                   // (The round-3 issue-cost probes -- 64 / 128 / 256 / 512: every strip staging the same pixels, degenerate per-lane
+                   // address patterns, one active lane per piece -- are gone from the product source: they rewrote addresses that the
+                   // border path takes relative to a clamped origin, and one of them faulted on the GPU box when applied there.
+                   // What they measured is in profiles/r03_ablate_wgrad43_dma.txt.)
 #endif
+static_assert((G4_DBG & ~(1 | 4 | 8 | 16 | 32)) == 0, "unknown G4_DBG bit: the address-rewriting probes were removed (see above)");
 #ifndef G4_STAGE_REGS
 #define G4_STAGE_REGS 0   // 1: raw tiles through registers (buffer_load_dwordx4 in steps 0..10, ds_write_b128 seven steps later) instead of LDS-DMA
 #endif
@@ -499,16 +502,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
         unsigned xb = 0, gb = 0;
         const bool more = sn < s_end && !(G4_DBG & 8);
         const bool inner = more && strip_origin(sn, y0, x0, xb, gb);
-        if (G4_DBG & 64) { xb = (unsigned)(d.IW + 1) * xcs; gb = 0; }   // dev: every strip stages the same (L2-resident) pixels
         if (!(G4_DBG & 4)) {
             float oa[2], ob[2][3];
             g4_load_ops<0>(vlane, oa[0], ob[0]);
             if ((G4_DBG & 32) && inner) stage_interior(xb, gb);
             Pat pt = load_patterns();
-            // dev probes of the piece issue cost (interior pieces only; results are wrong): every lane the same 16 bytes / one
-            // contiguous KB per piece, both inside the strip's own pixels
-            if (G4_DBG & 128) pt.g0 = pt.g1 = pt.g2 = pt.x0 = pt.x1 = pt.x2 = xcs;
-            if (G4_DBG & 256) pt.g0 = pt.g1 = pt.g2 = pt.x0 = pt.x1 = pt.x2 = xcs + (lane & 7) * 16 + (lane >> 3) * xcs;
             if constexpr (G4_STAGE_REGS) {
                 constexpr int LAG = 5;                       // steps between a load and its LDS write (5 x 192 MFMA cycles)
                 f32x4 stg[11];
@@ -560,7 +558,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino43_kernel(const adh_con
                 g4_contract<0>(acc, vlane, oa, ob, [&](auto stc) {
                     constexpr int ST = decltype(stc)::value;
                     if constexpr (ST < 11 && !(G4_DBG & 32)) {
-                        if ((G4_DBG & 512) ? (inner && lane == 0) : inner) {   // 512: one lane per piece (16 B land in LDS)
+                        if (inner) {
                             if constexpr (ST < 6) lean(gr, mg + ST * 1024, ST % 3 == 0 ? pt.g0 : (ST % 3 == 1 ? pt.g1 : pt.g2), ST < 3 ? sg0 : sg1);
                             else if constexpr (ST < 9) lean(xr, mx + (ST - 6) * 1024, ST == 6 ? pt.x0 : (ST == 7 ? pt.x1 : pt.x2), sx);
                             else if constexpr (ST == 9) {

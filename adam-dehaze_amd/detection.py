@@ -265,16 +265,55 @@ class FasterRCNN(nn.Module):
         if M == 0:
             return torch.empty(0, dtype=torch.int64, device=boxes.device)
         order = torch.sort(scores, descending=True, stable=True).indices
-        if M > 16384:        # the mask kernel's limit; beyond it only the 16384 best-scoring candidates compete (never reached with
-            order = order[:16384]   # trained weights: RPN sets hold <= 5000 boxes, score-thresholded detections far fewer)
-            M = 16384
-        b = boxes[order].contiguous()
-        g = groups[order].to(torch.int32).contiguous()
+        if M <= FasterRCNN.NMS_LIMIT:
+            return order[FasterRCNN._nms_sorted(boxes[order], groups[order], thr)]
+        # More candidates than the mask kernel takes at once (this used to drop everything beyond the 16384 best-scoring
+        # boxes, silently differing from torchvision.batched_nms -- reachable with flat softmax scores: R * (NC - 1) ~ 90 k box-head
+        # candidates per image before the score filter).  Batched NMS is independent per group, so each group goes through on its own;
+        # a group that is itself too large is cut into score-ordered chunks: a chunk's boxes are first suppressed by the boxes ALREADY
+        # KEPT (all of higher score), then by each other -- exactly the greedy algorithm.
+        kept = []
+        gs = groups[order]
+        for gid in torch.unique(gs).tolist():
+            idx = order[gs == gid]                      # this group's boxes, by descending score
+            mine: List[torch.Tensor] = []
+            for lo in range(0, idx.numel(), FasterRCNN.NMS_LIMIT):
+                cand = idx[lo:lo + FasterRCNN.NMS_LIMIT]
+                for prev in mine:                       # (chunked: at most NMS_LIMIT x NMS_LIMIT IoUs at a time)
+                    if cand.numel() == 0:
+                        break
+                    cand = cand[(FasterRCNN._iou(boxes[cand], boxes[prev]) <= thr).all(dim=1)]
+                if cand.numel():
+                    z = torch.zeros(cand.numel(), dtype=torch.int32, device=boxes.device)
+                    mine.append(cand[FasterRCNN._nms_sorted(boxes[cand], z, thr)])
+            kept.extend(mine)
+        keep = torch.cat(kept)
+        return keep[torch.sort(scores[keep], descending=True, stable=True).indices]
+
+    NMS_LIMIT = 16384      # boxes adh_nms_sorted takes in one launch
+
+    @staticmethod
+    def _iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """torchvision.ops.box_iou."""
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        lt = torch.max(a[:, None, :2], b[None, :, :2])
+        rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+    @staticmethod
+    def _nms_sorted(b: torch.Tensor, g: torch.Tensor, thr: float) -> torch.Tensor:
+        """Boolean keep mask of score-sorted boxes `b` with group ids `g` (one launch of the mask kernel + scan)."""
+        M = b.shape[0]
+        b = b.contiguous()
+        g = g.to(torch.int32).contiguous()
         words = H.value("adh_nms_words", M)
-        mask = torch.empty(M * words, device=boxes.device, dtype=torch.int64)
-        keep = torch.empty(M, device=boxes.device, dtype=torch.int32)
+        mask = torch.empty(M * words, device=b.device, dtype=torch.int64)
+        keep = torch.empty(M, device=b.device, dtype=torch.int32)
         H.call("adh_nms_sorted", b.data_ptr(), g.data_ptr(), M, float(thr), mask.data_ptr(), keep.data_ptr())
-        return order[keep.bool()]
+        return keep.bool()
 
     def proposals(self, rpn_out, image_size) -> List[torch.Tensor]:
         """rpn.filter_proposals: per level top-k by logit, sigmoid, small-box removal, NMS per level, first post_nms_top_n."""
@@ -359,6 +398,9 @@ class FasterRCNN(nn.Module):
         batch, image_size = self.transform(eng, x, pre_affine)
         feats = self.features(eng, batch)
         props = self.proposals(self.rpn_outputs(eng, feats, image_size, (batch.Hh, batch.Ww)), image_size)
+        if sum(int(p_.shape[0]) for p_ in props) == 0:    # no proposal survived the RPN filter: empty detections, as torchvision returns
+            return [{"boxes": torch.zeros((0, 4), device=x.device), "labels": torch.zeros(0, dtype=torch.int64, device=x.device),
+                     "scores": torch.zeros(0, device=x.device)} for _ in range(N)]
         cls, reg, rois = self.box_head_outputs(eng, feats, props, image_size)
         dets = self.detections(cls, reg, rois, image_size, N)
         # transform.postprocess: back to the input frame

@@ -110,6 +110,14 @@ def build_joint_system(config, world_size: int = 1, adam_duplicates: str = "sequ
     if world_size > 1:
         # a hard router leaves the branches a rank did not route to without gradients: agree on who produced what
         hard = config.get("routing", {}).get("type", "soft") == "hard"
+        if hard and _sync_bn(config):
+            # HardRouter skips a branch whose sub-batch is empty on a rank (routing.py): with sync-BN every rank must issue the SAME
+            # sequence of per-BatchNorm all-reduces, forward and backward -- a rank that skips a branch would deadlock the others
+            # or, worse, pair [2C+1] vectors of different layers.  The reference is single-process; the combination
+            # has no meaning to preserve, so it is refused rather than emulated with zero-count dummy collectives.
+            raise ValueError("routing.type 'hard' cannot be combined with parallel.sync_bn at world_size > 1: a rank whose "
+                             "sub-batch for a branch is empty would skip that branch's BatchNorm collectives; use replica-BN "
+                             "(the default) or a soft / gated router")
         sync = GradientSynchronizer(list(router.parameters()), world_size, detect_unused=hard, sync_bn=_sync_bn(config))
         sync.broadcast_parameters(router)
         sync.install()
@@ -532,17 +540,66 @@ def train_dehazing_model(config, intensity_level: str, train_loader=None, val_lo
     return model, [float(x) for x in losses]
 
 
+def _rank0_only(fn):
+    """Run `fn` on rank 0 while the other ranks wait -- and make sure they stop waiting: rank 0 reaches the hand-off in a
+    `finally`, broadcasts whether it succeeded, and the others exit non-zero if it did not (a rank 0 that raised
+    left the others in a barrier until the collective timeout).  The wait itself is a store-based monitored barrier with a
+    long timeout when the backend offers one (gloo), so a long evaluation does not trip RCCL's 10-minute watchdog."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        world, rank = _world_rank()
+        if world <= 1:
+            return fn(*a, **k)
+        import datetime
+        import torch.distributed as dist
+        ok, result, err = 1, None, None
+        if rank == 0:
+            try:
+                result = fn(*a, **k)
+            except BaseException as e:     # noqa: BLE001 -- the others must be told before it propagates
+                ok, err = 0, e
+        group = _eval_wait_group()
+        flag = torch.tensor([ok], dtype=torch.int32)
+        try:
+            dist.monitored_barrier(group=group, timeout=datetime.timedelta(hours=12))
+        except (RuntimeError, ValueError, AttributeError):
+            dist.barrier(group=group)
+        dist.broadcast(flag, src=0, group=group)
+        if err is not None:
+            raise err
+        if int(flag.item()) == 0:
+            raise SystemExit(f"rank {rank}: rank 0 failed in {fn.__name__}; exiting")
+        return result
+    return wrapper
+
+
+_EVAL_GROUP = None
+
+
+def _eval_wait_group():
+    """A gloo group for the long rank-0-only waits (created once, by every rank, the first time it is needed)."""
+    global _EVAL_GROUP
+    import datetime
+    import torch.distributed as dist
+    if _EVAL_GROUP is None:
+        try:
+            _EVAL_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=12))
+        except (RuntimeError, ValueError):
+            _EVAL_GROUP = dist.group.WORLD
+    return _EVAL_GROUP
+
+
+@_rank0_only
 def evaluate_joint_model(config, test_loader=None, steps: int = 2, use_lpips: bool = True):
     """evaluation/evaluate.py:94-177 (image-quality part): load the joint checkpoint if present, route every test
     batch, accumulate PSNR / SSIM / LPIPS per intensity category on the device, print and save
     `<evaluation.results_dir>/joint_model_results.json` (schema of evaluation/metrics.py:117-124)."""
     from .metrics import CATEGORY_BY_LABEL, ImageQualityMetrics
+    # (every rank scoring its own shard and writing the same JSON concurrently was a race, ADVICE r2: rank 0 evaluates and
+    # writes, the others wait for it in _rank0_only)
     world, rank = _world_rank()
-    if world > 1 and rank != 0:
-        # every rank scoring its own shard and writing the same JSON concurrently was a race (ADVICE r2): rank 0 evaluates
-        # and writes, the others wait for it
-        _barrier()
-        return None
     system = build_joint_system(config, 1)
     dev = system["device"]
     ck = os.path.join(config["joint_training"]["checkpoint_dir"], "best_model.pth")
@@ -571,20 +628,16 @@ def evaluate_joint_model(config, test_loader=None, steps: int = 2, use_lpips: bo
     results = metrics.print_results()
     out_dir = config.get("evaluation", {}).get("results_dir", "results")
     metrics.save_results(os.path.join(out_dir, "joint_model_results.json"))
-    if world > 1:
-        _barrier()
     return results
 
 
+@_rank0_only
 def evaluate_baseline_models(config, test_loader=None, steps: int = 2, use_lpips: bool = True):
     """evaluation/evaluate.py:32-92: every test image through the branch model of its ground-truth fog intensity (no classifier,
     no router), PSNR / SSIM / LPIPS per category on the device, `<evaluation.results_dir>/baseline_results.json`.  The reference
     runs one image at a time; eval-mode branches are per-sample independent, so the images of a level go through as one batch."""
     from .metrics import CATEGORY_BY_LABEL, ImageQualityMetrics
     world, rank = _world_rank()
-    if world > 1 and rank != 0:
-        _barrier()
-        return None
     system = build_joint_system(config, 1)
     dev = system["device"]
     for level, m in system["models"].items():
@@ -607,8 +660,6 @@ def evaluate_baseline_models(config, test_loader=None, steps: int = 2, use_lpips
                                       [CATEGORY_BY_LABEL[lab]] * int(idx.numel()))
     results = metrics.print_results()
     metrics.save_results(os.path.join(config.get("evaluation", {}).get("results_dir", "results"), "baseline_results.json"))
-    if world > 1:
-        _barrier()
     return results
 
 
@@ -650,7 +701,7 @@ def run_comprehensive_evaluation(config, steps: int = 2, use_lpips: bool = True)
               f"  Detection on Dehazed Images mAP: {deh_o['mAP']:.4f}\n  Improvement: {improvement:.2f}%")
     comprehensive = {"baseline": baseline, "joint": joint,
                      "detection": {"hazy": hazy_o, "dehazed": deh_o, "improvement_percent": improvement,
-                                   "counts": det.get("counts")},
+                                   "counts": det.get("counts"), "weights": det.get("weights")},
                      "comparison": {"baseline_avg_psnr": b_psnr, "joint_avg_psnr": j_psnr, "psnr_improvement": j_psnr - b_psnr}}
     with open(os.path.join(out_dir, "comprehensive_results.json"), "w") as f:
         json.dump(comprehensive, f, indent=2)
@@ -658,6 +709,7 @@ def run_comprehensive_evaluation(config, steps: int = 2, use_lpips: bool = True)
     return comprehensive
 
 
+@_rank0_only
 def evaluate_detection(config, test_loader=None, steps: int = 1, score_threshold: float = 0.5, annotation_file=None):
     """Detection half of evaluation/evaluate.py:179-383 on device: the detector on the hazy frames and on the routed (dehazed)
     frames, detections with score > 0.5 (evaluate.py:327,343) converted to COCO [x, y, w, h], counted per intensity category and
@@ -671,14 +723,33 @@ def evaluate_detection(config, test_loader=None, steps: int = 1, score_threshold
     from .detection import create_detection_model, create_integrated_system, filter_detections
     from .metrics import CATEGORY_BY_LABEL, DetectionMetrics
     world, rank = _world_rank()
-    if world > 1 and rank != 0:
-        _barrier()
-        return None
     system = build_joint_system(config, 1)
     dev = system["device"]
+    # evaluation/evaluate.py:201-227: the JOINT checkpoint into classifier + router + branches, and the detector's own
+    # checkpoint when there is one (this used to score 'dehazed' detections with the pre-joint weights and an always
+    # random-init detector).  What was used goes into the results file.
+    weights = {"joint_checkpoint": None, "detector_checkpoint": None}
+    ck = os.path.join(config["joint_training"]["checkpoint_dir"], "best_model.pth")
+    if os.path.exists(ck):
+        c = torch.load(ck, map_location="cpu")
+        system["router"].load_state_dict(c["router_state_dict"])
+        weights["joint_checkpoint"] = ck
+        print(f"Loaded joint model from {ck}")
+    else:
+        print(f"Joint checkpoint {ck} not found. Using the individually loaded / random weights.")
     cfg = dict(config)
     cfg.setdefault("detection", {"model": "faster_rcnn_resnet50_fpn", "pretrained": False})
     detector = create_detection_model(cfg).to(dev).eval()
+    dck = os.path.join(str(cfg["detection"].get("checkpoint_dir", "checkpoints/detection")), "best_model.pth")
+    if os.path.exists(dck):
+        c = torch.load(dck, map_location="cpu")
+        detector.load_state_dict(c["model_state_dict"] if "model_state_dict" in c else c)
+        weights["detector_checkpoint"] = dck
+        print(f"Loaded detection model from {dck}")
+    else:
+        print(f"Detection checkpoint {dck} not found: the detector runs on its "
+              f"{'pretrained' if cfg['detection'].get('pretrained') else 'RANDOM-INIT'} weights (its detections carry no meaning then).")
+    weights["detector_random_init"] = weights["detector_checkpoint"] is None and not cfg["detection"].get("pretrained")
     system["classifier"].eval()
     for m in system["models"].values():
         m.eval()
@@ -724,9 +795,9 @@ def evaluate_detection(config, test_loader=None, steps: int = 1, score_threshold
     out_dir = config.get("evaluation", {}).get("results_dir", "results")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "detection_results.json"), "w") as f:
-        json.dump({"score_threshold": score_threshold, "counts": counts, "detections": records}, f, indent=1)
+        json.dump({"score_threshold": score_threshold, "weights": weights, "counts": counts, "detections": records}, f, indent=1)
     print(f"Detections with score > {score_threshold}: hazy {counts['hazy']}, dehazed {counts['dehazed']}")
-    results = {"counts": counts}
+    results = {"counts": counts, "weights": weights}
     if dm is not None:
         for tag, title in (("hazy", "Hazy"), ("dehazed", "Dehazed")):
             print(f"\nObject Detection on {title} Images:")
@@ -740,6 +811,4 @@ def evaluate_detection(config, test_loader=None, steps: int = 1, score_threshold
                 print(f"\n{intensity.capitalize()} Intensity:\n  Hazy mAP: {hm:.4f}\n  Dehazed mAP: {dmap:.4f}")
                 if hm != 0:
                     print(f"  Improvement: {(dmap - hm) / hm * 100:.2f}%")
-    if world > 1:
-        _barrier()
     return results

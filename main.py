@@ -81,11 +81,22 @@ def main():
         to fail with a KeyError deep in the loader); the other stages of a multi-stage mode start fresh."""
         if args.resume is None or args.resume is True:
             return args.resume
-        owner = T.checkpoint_stage(args.resume, config)
-        if owner != stage:
-            print(f"--resume {args.resume}: a '{owner}' checkpoint; stage '{stage}' does not resume from it")
+        if resume_owner != stage:
+            print(f"--resume {args.resume}: a '{resume_owner}' checkpoint; stage '{stage}' does not resume from it")
             return None
         return args.resume
+    # `--resume <file>`: resolve the stage that wrote the file ONCE (checkpoint_stage reads the file and compares key sets), and
+    # refuse a mode that runs no such stage -- it used to print a note per stage, train from scratch and overwrite best_model.pth
+    # although the user asked to resume (ADVICE r3)
+    resume_owner = None
+    if isinstance(args.resume, str):
+        resume_owner = T.checkpoint_stage(args.resume, config)
+        stages = {"train_joint": ("joint",), "train_dehazing": ("low", "medium", "high"),
+                  "train_all": ("low", "medium", "high", "joint")}.get(args.mode, ())
+        if stages and resume_owner not in stages:
+            raise SystemExit(f"--resume {args.resume} is a '{resume_owner}' checkpoint, but --mode {args.mode} runs only the "
+                             f"stage(s) {', '.join(stages)}: nothing would resume from it (and training from scratch would "
+                             "overwrite best_model.pth).  Pick the matching --mode, or drop --resume.")
     if args.mode == "train_joint":
         T.train_joint_model(config, epochs=args.epochs, resume=resume_for("joint"))
     elif args.mode == "train_dehazing":

@@ -63,6 +63,38 @@ def test_nms_kernel_matches_the_sequential_definition():
         assert torch.equal(got, want), (M, ngroups)
 
 
+def test_nms_beyond_the_kernel_limit_is_exact_and_no_proposals_give_empty_detections(monkeypatch):
+    """more candidates than one launch of the mask kernel takes (16384) used to be truncated to the best-scoring
+    16384; now every group goes through on its own and an oversized group in score-ordered chunks (suppressed first by what
+    earlier chunks kept) -- the greedy algorithm exactly.  Checked against the sequential definition with the limit lowered
+    (several groups, and ONE group larger than the limit), and at a real size with two different chunkings agreeing.  And a
+    frame whose RPN filter leaves no proposal returns empty detections instead of failing in adh_roi_align_fpn."""
+    g = torch.Generator().manual_seed(5)
+
+    def case(M, ngroups):
+        c = torch.rand(M, 2, generator=g) * 300
+        wh = torch.rand(M, 2, generator=g) * 60 + 2
+        return torch.cat([c, c + wh], dim=1), torch.rand(M, generator=g), torch.randint(0, ngroups, (M,), generator=g)
+    monkeypatch.setattr(D.FasterRCNN, "NMS_LIMIT", 256)
+    for M, ngroups in ((1500, 5), (1500, 1), (257, 1)):
+        boxes, scores, groups = case(M, ngroups)
+        want = R.det_nms(boxes, scores, groups, 0.5)
+        got = D.FasterRCNN.nms(boxes.to(DEV), scores.to(DEV), groups.to(DEV), 0.5).cpu()
+        assert torch.equal(got, want), (M, ngroups)
+    boxes, scores, groups = case(20000, 3)
+    monkeypatch.setattr(D.FasterRCNN, "NMS_LIMIT", 16384)
+    a = D.FasterRCNN.nms(boxes.to(DEV), scores.to(DEV), groups.to(DEV), 0.5).cpu()
+    monkeypatch.setattr(D.FasterRCNN, "NMS_LIMIT", 3000)
+    b = D.FasterRCNN.nms(boxes.to(DEV), scores.to(DEV), groups.to(DEV), 0.5).cpu()
+    assert torch.equal(a, b) and a.numel() > 100
+    # no proposals
+    torch.manual_seed(0)
+    det = D.FasterRCNN(num_classes=5).to(DEV).eval()
+    monkeypatch.setattr(D.FasterRCNN, "proposals", lambda self, rpn_out, image_size: [torch.zeros((0, 4), device=DEV) for _ in range(2)])
+    out = det(torch.rand(2, 3, 64, 96, device=DEV))
+    assert len(out) == 2 and all(d["boxes"].shape == (0, 4) and d["scores"].numel() == 0 and d["labels"].dtype == torch.int64 for d in out)
+
+
 def test_roi_align_fpn_matches_torchvision_semantics():
     g = torch.Generator().manual_seed(5)
     feats = [torch.randn(2, 256, h, w, generator=g) for h, w in ((40, 56), (20, 28), (10, 14), (5, 7))]

@@ -224,6 +224,54 @@ def test_two_by_two_tap_weight_gradients_full_size(kind, Ci, Co, w32, monkeypatc
     assert float((got - want).abs().max()) < 5e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("C,Hh,Ww", [(96, 512, 1024), (384, 128, 256)])
+def test_three_by_three_weight_gradient_full_size_rank_one(C, Hh, Ww):
+    """conv_wgrad_wino43_kernel (the default 3x3 stride-1 weight gradient since round 3, 21 % of the headline step) at the
+    headline shapes, 8 x 512 x 1024 x 96 -> 96 and 8 x 128 x 256 x 384 -> 384, with the per-XCD pixel split the engine picks,
+    against an INDEPENDENT answer (until now the full-size check was whole batch = sum of per-image
+    launches, and the fp64-definition checks stopped at 40 x 200 pixels): rank-one inputs x = a (x) u, dL/dy = b (x) v give
+    dW[co][ci][ky][kx] = v[co] u[ci] corr[ky][kx] with corr = sum over pixels of a shifted by the tap times b, evaluated in fp64
+    with shifted slices.  Replaces the same autograd weight gradient (/root/reference models/dehazing/base_model.py:11-13)."""
+    import adam_dehaze_amd.engine as E
+    eng = _eng()
+    w = torch.zeros(C, C, 3, 3, device=DEV, requires_grad=True)
+    plans = eng._launch_plan("conv", 3, 1, 1, w, "fwd")
+    calls = []
+    real_call = H.call
+
+    def counting(name, *a_, **k_):
+        calls.append(name)
+        return real_call(name, *a_, **k_)
+    a, b = _randn(N, Hh, Ww, seed=21), _randn(N, Hh, Ww, seed=22)
+    u, v = _randn(C, seed=23), _randn(C, seed=24)
+    x = (a[..., None] * u).contiguous()
+    g = (b[..., None] * v).contiguous()
+    H.call = counting
+    try:
+        got = eng._wgrad(plans, Act(x), g, C, w).double()
+    finally:
+        H.call = real_call
+    assert "adh_conv_wgrad_wino43" in calls, calls         # the kernel under test is the one the engine takes by default
+    ap = F.pad(a.double(), (1, 1, 1, 1))
+    corr = torch.zeros(3, 3, dtype=torch.float64, device=DEV)
+    bd = b.double()
+    for ky in range(3):
+        for kx in range(3):
+            corr[ky, kx] = (ap[:, ky:ky + Hh, kx:kx + Ww] * bd).sum()
+    want = v.double()[:, None, None, None] * u.double()[None, :, None, None] * corr[None, None]
+    torch.cuda.synchronize()
+    # sums of 0.26-4.2 M products of O(1) terms in fp32 tiles, split sums in fp32: ~ sqrt(P) * 1e-7 of sqrt(P)-sized sums
+    assert float((got - want).abs().max()) < 5e-5 * float(want.abs().max())
+    # and on generic inputs: the whole batch against the sum of per-image launches (different pixel splits, same answer)
+    x, g = _randn(N, Hh, Ww, C, seed=25), _randn(N, Hh, Ww, C, seed=26)
+    whole = eng._wgrad(plans, Act(x), g, C, w).double()
+    parts = torch.zeros_like(whole)
+    for n in range(N):
+        parts += eng._wgrad(plans, Act(x[n:n + 1].contiguous()), g[n:n + 1].contiguous(), C, w).double()
+    torch.cuda.synchronize()
+    assert float((whole - parts).abs().max()) < 2e-5 * float(parts.abs().max())
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # (b) train-mode ConvBlock 96 -> 96 at 8 x 512 x 1024: BatchNorm statistics over 4.2 M pixels per channel
 # ---------------------------------------------------------------------------------------------------------------------

@@ -134,3 +134,21 @@ def test_config2_pipeline_8x512x1024():
             assert float((out_low[i:i + 1] - models["low"](xi)).abs().max()) < 1e-6
             assert float((out_auto[i:i + 1] - models[names[int(want[i])]](xi)).abs().max()) < 1e-6
     assert bool(info_low["low_mask"].all()) and float((out_low - x).abs().max()) > 1e-3
+
+
+def test_complex_fullwidth_512x1024_vs_oracle(monkeypatch):
+    """The whole full-width CORUN-Complex at the HEADLINE resolution against the CPU oracle (VERDICT r3 weak 1 / next 1a;
+    /root/reference models/dehazing/high_intensity.py:92-138): one 512 x 1024 frame, default kernels.  Eval output and train-mode
+    output within 1e-3 (north-star) and PSNR > 60 dB, L1 loss within 1e-4, every BatchNorm buffer within 1e-4, and a spread of
+    parameter gradients -- stem, both encoder levels, bottleneck, both decoder levels (ConvTranspose and ResidualBlock), both
+    head convolutions, the guidance branch, a BatchNorm affine pair and a CBAM MLP -- on the kink-matched float64 gate at 5e-4
+    of each tensor's scale (tests/test_gpu_parity.py _fullwidth_vs_oracle; the float64 oracle with the kernels' own ReLU
+    masks replayed is the exact gradient of the piece of the network the HIP path differentiated)."""
+    from tests.test_gpu_parity import _fullwidth_vs_oracle
+    names = ["init_conv.block.0.weight", "encoder.0.0.block.0.weight", "encoder.0.1.conv1.block.0.weight", "encoder.0.3.fc.0.weight",
+             "encoder.1.0.block.0.weight", "encoder.1.2.conv2.block.0.weight", "bottleneck.0.conv1.block.0.weight",
+             "bottleneck.2.conv2.block.1.weight", "bottleneck.2.conv2.block.1.bias", "decoder.0.0.weight", "decoder.0.3.conv1.block.0.weight",
+             "decoder.1.0.weight", "decoder.1.3.conv2.block.0.weight", "output_conv.0.block.0.weight", "output_conv.1.block.0.weight",
+             "output_conv.2.weight", "detail_branch.0.block.0.weight", "detail_branch.2.weight"]
+    _fullwidth_vs_oracle("complex96", "f43", 1, 512, 1024, monkeypatch, grad_names=names, grad_tol=5e-4,
+                         report="grad_gate_fullwidth_512x1024.txt")

@@ -2,6 +2,7 @@
 import ctypes
 import hashlib
 import os
+import sys
 import re
 
 import numpy as np
@@ -171,7 +172,8 @@ def test_counted_wait_kernels_have_no_scratch_traffic(tmp_path):
                 cur = None
             elif cur and ("scratch_" in line or "v_mfma" in line or "flat_load" in line or "flat_store" in line):
                 kernels[cur].append("s" if "scratch_" in line else ("m" if "v_mfma" in line else "f"))
-    assert len(kernels) == 12, sorted(kernels)         # NT = 1, 2, 3 of the three kernels + conv_wino43_kernel<NT, BNRED = true>
+    # NT = 1, 2, 3 of the three kernels + conv_wino43_kernel<NT, BNRED = true>, and the bf16 x 3 forms of conv_wino43_kernel
+    assert len(kernels) == 18, sorted(kernels)
     for name, ops in kernels.items():
         seq = "".join(ops)
         assert "m" in seq, name
@@ -235,9 +237,9 @@ def _isa_lines(fn, tmpdir):
     code = []
     for ln in open(out).read().splitlines():
         t = ln.strip()
-        if not t or t.startswith((";", ".", "//")):
-            continue
         t = t.split(";")[0].split("//")[0].strip()
+        if not t or (t.startswith(".") and not (t.startswith(".LBB") and t.endswith(":"))):   # directives go, block labels stay
+            continue
         if ln.startswith("\t"):
             code.append(t)
         elif t.endswith(":"):
@@ -327,6 +329,107 @@ def test_no_valu_write_within_two_wait_states_of_an_mfma_operand_read(fn, tmp_pa
                 for b in back.get(j, []):
                     check_window(k, between + list(range(b - 1, max(b - 8, -1), -1)), "via branch at %d" % b)
     assert nmfma >= (8 if fn != "conv_igemm.hip" else 4), (fn, nmfma)
+
+
+def _vm_inflight_violations(code):
+    """Walk a linear instruction list: a register an inline-asm / compiler vector-memory LOAD is still filling (issued, not yet
+    covered by an `s_waitcnt vmcnt(N)`: vmcnt retires in issue order, stores and LDS-DMA pieces count too) must not be read or
+    written by any other instruction.  hipcc does not know that the asm statements of the counted-wait kernels are loads: it is
+    free to COPY such a register (live-range split, loop-carried ring resolved at the back edge) right behind the load -- the
+    copy then holds the old contents.  Seen in round 4 on conv_wino43_kernel<3, false, true> with weights requested across the
+    chunk boundary (csrc/conv_wino43.hip, w4b_groups).  Loop bodies are walked twice (state carried over the back edge)."""
+    labels = {ln[:-1]: i for i, ln in enumerate(code) if ln.endswith(":")}
+    bad = []
+
+    def all_regs(ln):
+        t = ln.split(None, 1)
+        out = set()
+        if len(t) > 1:
+            for tok in re.split(r"[ ,]+", t[1]):
+                out |= _regs(tok)
+        return out
+
+    def walk(lo, hi, queue, depth):
+        k = lo
+        while k < hi:
+            ln = code[k]
+            if ln.endswith(":"):
+                k += 1
+                continue
+            t = ln.split(None, 1)
+            op = t[0]
+            if op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", ln)
+                if m:
+                    n = int(m.group(1))
+                    while len(queue) > n:
+                        queue.pop(0)
+            elif op.startswith(("global_load", "buffer_load", "scratch_load", "flat_load")):
+                inflight = set().union(*[q for q in queue if q]) if queue else set()
+                dst = _regs(t[1].split(",")[0]) if " lds" not in ln and not ln.rstrip().endswith("lds") else set()
+                srcs = all_regs(ln) - dst
+                if (srcs | dst) & inflight:
+                    bad.append((k, ln))
+                queue.append(dst)
+            elif op.startswith(("global_store", "buffer_store", "scratch_store", "flat_store", "global_atomic", "buffer_atomic")):
+                inflight = set().union(*[q for q in queue if q]) if queue else set()
+                if all_regs(ln) & inflight:
+                    bad.append((k, ln))
+                queue.append(set())
+            else:
+                inflight = set().union(*[q for q in queue if q]) if queue else set()
+                if inflight and all_regs(ln) & inflight:
+                    bad.append((k, ln))
+                if op.startswith(("s_cbranch", "s_branch")) and t[-1].split()[-1] in labels and depth < 1:
+                    tgt = labels[t[-1].split()[-1]]
+                    if tgt < k:      # back edge: once more round the loop with what is in flight now
+                        walk(tgt, k, list(queue), depth + 1)
+            k += 1
+
+    walk(0, len(code), [], 0)
+    return bad
+
+
+@pytest.mark.parametrize("fn", ["conv_wino43.hip"])
+def test_no_register_is_touched_while_its_asm_load_is_in_flight(fn, tmp_path_factory):
+    """See _vm_inflight_violations: every instantiation of conv_wino43_kernel, fp32 and bf16 x 3 forms.  (conv_wino.hip's main
+    loops branch between edge and interior staging paths: a linear walk double-counts their pieces; its contract is covered by
+    the bit-equal / direct-path parity tests on the GPU.)"""
+    code = _isa_lines(fn, tmp_path_factory.getbasetemp())
+    # split into functions at their labels (kernels start with _Z...:) so that state does not leak across kernels
+    starts = [i for i, ln in enumerate(code) if ln.startswith("_Z") and ln.endswith(":")] + [len(code)]
+    nk = 0
+    for a, b in zip(starts[:-1], starts[1:]):
+        if "conv_wino" not in code[a]:
+            continue
+        fcode = code[a:b]
+        mf = [i for i, ln in enumerate(fcode) if ln.startswith("v_mfma")]
+        labels = {ln[:-1]: i for i, ln in enumerate(fcode) if ln.endswith(":")}
+        # the main loop = the smallest backward branch span that contains every MFMA of the contraction (the epilogue's
+        # `if (residual) load` blocks are branchy and compiler-waited: a linear walk over them would see phantom overlaps)
+        loops = []
+        for j, ln in enumerate(fcode):
+            t = ln.split()
+            if t and t[0].startswith(("s_cbranch", "s_branch")) and t[-1] in labels and labels[t[-1]] < j:
+                if labels[t[-1]] <= mf[0] and j >= mf[-1]:
+                    loops.append((j - labels[t[-1]], labels[t[-1]], j))
+        assert loops, code[a]
+        _, lo, hi = min(loops)
+        nk += 1
+        bad = _vm_inflight_violations(fcode[lo:hi + 1])
+        assert not bad, (fn, code[a], bad[:4])
+    assert nk >= 6
+
+
+def test_inflight_walker_flags_a_planted_copy():
+    ld = "global_load_dwordx4 v[4:7], v1, s[2:3]"
+    assert _vm_inflight_violations([ld, "v_mov_b32_e32 v9, v5", "s_waitcnt vmcnt(0)"])
+    assert not _vm_inflight_violations([ld, "s_waitcnt vmcnt(0)", "v_mov_b32_e32 v9, v5"])
+    assert not _vm_inflight_violations([ld, "global_load_dwordx4 v[8:11], v1, s[2:3]", "s_waitcnt vmcnt(1)", "v_mov_b32_e32 v20, v5"])
+    assert _vm_inflight_violations([ld, "global_load_dwordx4 v[8:11], v1, s[2:3]", "s_waitcnt vmcnt(1)", "v_mov_b32_e32 v20, v9"])
+    # a loop whose back edge carries a load into a copy at the top
+    loop = ["top:", "v_mov_b32_e32 v20, v5", "s_waitcnt vmcnt(0)", ld, "s_cbranch_scc1 top"]
+    assert _vm_inflight_violations(loop)
 
 
 def test_mfma_hazard_walker_flags_a_planted_violation():
@@ -442,6 +545,40 @@ def test_explicit_resume_file_goes_to_the_stage_that_wrote_it(tmp_path):
     torch.save({"epoch": 1}, str(tmp_path / "junk.pth"))
     with pytest.raises(ValueError):
         T.checkpoint_stage(str(tmp_path / "junk.pth"), cfg)
+
+
+def test_hard_routing_with_sync_bn_and_mismatched_resume_are_refused(tmp_path, monkeypatch):
+    """ADVICE r3.  (i) routing.type 'hard' + parallel.sync_bn at world_size > 1 would make ranks issue different sequences of
+    BatchNorm collectives (a rank skips a branch whose sub-batch is empty): build_joint_system raises ValueError.  (ii) `--resume
+    <file>` whose owner stage the selected --mode does not run used to print a note, train from scratch and overwrite
+    best_model.pth: main.py now exits before anything is trained."""
+    import importlib
+    import yaml
+    from adam_dehaze_amd import train as T
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "config.yaml")))
+    cfg["device"] = "cpu"
+    cfg["classifier"]["pretrained"] = False
+    cfg["classifier"]["checkpoint_dir"] = cfg["dehazing"]["checkpoint_dir"] = str(tmp_path / "none")
+    for lvl, ch in (("low", 8), ("medium", 8), ("high", 16)):
+        cfg["dehazing"][lvl]["channels"] = ch
+    cfg["routing"]["type"] = "hard"
+    cfg["parallel"] = {"sync_bn": True}
+    with pytest.raises(ValueError, match="sync_bn"):
+        T.build_joint_system(cfg, world_size=2)
+    # (ii)
+    pj = str(tmp_path / "joint.pth")
+    torch.save({"epoch": 1, "router_state_dict": {}}, pj)
+    mod = importlib.import_module("main")
+    cfgp = str(tmp_path / "cfg.yaml")
+    cfg.pop("parallel")
+    cfg["routing"]["type"] = "soft"
+    yaml.safe_dump(cfg, open(cfgp, "w"))
+    monkeypatch.setattr(sys, "argv", ["main.py", "--mode", "train_dehazing", "--config", cfgp, "--resume", pj, "--device", "cpu"])
+    called = []
+    monkeypatch.setattr(T, "train_dehazing_model", lambda *a, **k: called.append("trained"))
+    with pytest.raises(SystemExit, match="joint"):
+        mod.main()
+    assert called == []
 
 
 def test_detector_surface_and_torchvision_key_names():

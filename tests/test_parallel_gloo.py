@@ -240,6 +240,51 @@ def _worker_validation_and_checkpoints(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _worker_selfcheck(rank, world, port, ret):
+    """GradientSynchronizer.selfcheck_result (bench.py prints it as `ddp_selfcheck` when world > 1): a clean step passes on every
+    rank; a bucket one rank corrupts after synchronisation, parameters that differ by one ulp on one rank, and a step that was
+    never armed are all reported as failures, by every rank alike."""
+    _init(rank, world, port)
+    from adam_dehaze_amd.parallel import GradientSynchronizer
+    params = _params()
+    sync = GradientSynchronizer(params, world, bucket_bytes=300, rebuild=False)
+    assert len(sync.buckets) >= 2
+
+    def step(corrupt=False, arm=True):
+        for p, g in zip(params, _rank_grads(rank)):
+            p.grad = g.clone()
+        if arm:
+            sync.begin_selfcheck()
+        sync.begin_step()
+        sync.finish()
+        if corrupt and rank == 1:
+            sync.arena[3] += 1e-3
+    step()
+    with torch.no_grad():
+        for p in params:                                  # identical "optimizer step" on identical synchronized gradients
+            p -= 0.1 * p.grad
+    good = sync.selfcheck_result(params)
+    ok = good["ok"] and good["backend"] == "gloo" and good["max_rel"] < 1e-6 and good["params_bit_equal"] and good["buckets"] == len(sync.buckets)
+    step(corrupt=True)
+    bad = sync.selfcheck_result(params)
+    ok &= (not bad["ok"]) and bad["max_rel_across_ranks"] > 1e-7
+    step(arm=False)
+    unarmed = sync.selfcheck_result(params)
+    ok &= (not unarmed["ok"]) and "error" in unarmed
+    step()
+    if rank == 1:
+        with torch.no_grad():
+            params[0].view(-1)[0] = torch.nextafter(params[0].view(-1)[0], torch.tensor(10.0))
+    drift = sync.selfcheck_result(params)
+    ok &= (not drift["ok"]) and drift["max_rel"] < 1e-6 and not drift["params_bit_equal"]
+    both = [None, None]
+    dist.all_gather_object(both, (good["ok"], bad["ok"], drift["ok"], unarmed["ok"]))
+    ok &= both[0] == both[1]
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _spawn(fn, base):
     world = 2
     mgr = mp.Manager()
@@ -255,6 +300,10 @@ def test_gradient_synchronizer_world2_gloo():
 
 def test_overlapped_protocol_rebuild_and_unused_world2_gloo():
     _spawn(_worker_hooks, 30100)
+
+
+def test_selfcheck_reports_clean_and_planted_failures_world2_gloo():
+    _spawn(_worker_selfcheck, 31300)
 
 
 def test_rank_agreements_world2_gloo():
