@@ -96,6 +96,9 @@ def _layout_key(L: WLayout) -> tuple:
 # Test hook (tests/_util.py: kink_matched): when a dict, every fused conv(+BN)+ReLU op stores its post-activation output
 # under id(weight), so a test can replay the ReLU masks this implementation actually used in the float64 oracle.
 RELU_CAPTURE: Optional[Dict[int, torch.Tensor]] = None
+# test hook (tests/_util.py kink_matched): {id(AttentionBlock fc.0.weight): (global max-pool arg-max [N, C], per-pixel channel
+# arg-max [N, H*W])} of every attention block run while it is a dict -- the other two kinks of the network besides the ReLUs
+CBAM_CAPTURE: Optional[Dict[int, Tuple[torch.Tensor, torch.Tensor]]] = None
 # Synchronised BatchNorm (parallel.GradientSynchronizer(sync_bn=True)): SYNC_BN(sums) all-reduces (SUM) the fp64 vector
 # [sum(C) | second row (C) | count] of one BatchNorm layer over the ranks, in place, ordered after the kernels enqueued so far
 # on the current stream; None = per-replica statistics.
@@ -981,6 +984,8 @@ class Engine:
         H.call("adh_cbam_apply", x.t.data_ptr(), x.cs, ca.data_ptr(), smap.data_ptr(), wsp.data_ptr(), N, Hh, Ww, Cc,
                sa.data_ptr(), out.data_ptr(), out.stride(2), work=2 * xbytes)
         o = Act(out, Cc)
+        if CBAM_CAPTURE is not None:
+            CBAM_CAPTURE[id(w1)] = (amax_idx, cidx)
         if self.record:
             self.use_param(wsp, w1, w2)
 

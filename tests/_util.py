@@ -58,12 +58,26 @@ class kink_matched:
         import adam_dehaze_amd.engine as E
         self._E = E
         self._old = E.RELU_CAPTURE
+        self._old_cbam = E.CBAM_CAPTURE
         E.RELU_CAPTURE = self.cap
+        self.cbam = {}
+        E.CBAM_CAPTURE = self.cbam
         return self
 
     def __exit__(self, *exc):
         self._E.RELU_CAPTURE = self._old
+        self._E.CBAM_CAPTURE = self._old_cbam
         return False
+
+    def cbam_indices(self):
+        """{AttentionBlock 'fc.0.weight' parameter name: (global max-pool arg-max [N, C], per-pixel channel arg-max [N, H*W])} on
+        the CPU: the arg-max positions the HIP attention kernels used (the network's other kinks; round 4)."""
+        out = {}
+        for name, p in self.model.named_parameters():
+            o = self.cbam.get(id(p))
+            if o is not None:
+                out[name] = (o[0].cpu(), o[1].cpu())
+        return out
 
     def masks(self):
         """{conv weight parameter name: bool mask [N, >=C, H, W] on the CPU} (channel padding of the NHWC buffers kept;
@@ -76,12 +90,15 @@ class kink_matched:
         return out
 
 
-def oracle_with_masks(fn, masks):
-    """Run `fn()` (an oracle forward + backward) with the ReLUs that follow the listed convolutions forced to `masks`."""
+def oracle_with_masks(fn, masks, cbam=None):
+    """Run `fn()` (an oracle forward + backward) with the ReLUs that follow the listed convolutions forced to `masks` and, given
+    `cbam` (kink_matched.cbam_indices()), the attention blocks' arg-max positions forced as well."""
     from oracle import ref_cpu as R
     old = R.KINK_MASKS
     R.KINK_MASKS = {k: m for k, m in masks.items()}
     old_relu = R._relu
+    old_cbam = R.CBAM_INDICES
+    R.CBAM_INDICES = cbam
 
     def _relu(y, key):
         m = masks.get(key)
@@ -94,3 +111,4 @@ def oracle_with_masks(fn, masks):
     finally:
         R._relu = old_relu
         R.KINK_MASKS = old
+        R.CBAM_INDICES = old_cbam

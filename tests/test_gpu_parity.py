@@ -349,9 +349,10 @@ def _fullwidth_vs_oracle(tag, algo, n, h, w, monkeypatch, grad_names=None, grad_
         assert abs(float(loss) - float(ref_loss)) < 1e-4
         out.backward(gout.to(DEV))
     grads_gpu = {name: p.grad.cpu().double() for name, p in m.named_parameters() if p.grad is not None}
-    masks = km.masks()
+    masks, cbam = km.masks(), km.cbam_indices()
     km.cap.clear()
-    _, sd64 = oracle_with_masks(lambda: oracle(torch.float64), masks)
+    km.cbam.clear()
+    _, sd64 = oracle_with_masks(lambda: oracle(torch.float64), masks, cbam)
     bad, lines = [], []
     for name, p in m.named_parameters():
         g64 = sd64[name].grad
