@@ -3,7 +3,8 @@
 `FogIntensityClassifier(model_name, num_classes=3, pretrained)` keeps the reference's constructor,
 `forward(x) -> (logits, features)`, `extract_features`, `feature_dim`, and torchvision-compatible
 state_dict keys (`backbone.*`, `classifier.{1,4}.*`).  Backbones built here:
-  resnet18 / resnet34  (reference default: resnet18, classifier.py:24-36)  -- forward and backward
+  resnet18 / resnet34 / resnet50  (reference default: resnet18, classifier.py:24-36; resnet50: Bottleneck
+                        [3, 4, 6, 3], feature_dim 2048, classifier.py:31-33)  -- forward and backward
   densenet121          (the north-star's HDEN backbone; the reference itself raises for this name,
                         classifier.py:69: build-side extension)             -- forward (eval) only
 Every other name raises ValueError like the reference does for unknown backbones (efficientnet /
@@ -69,10 +70,37 @@ class _BasicBlock(nn.Module):
                         training=tr)
 
 
-class _ResNet(nn.Module):
-    """torchvision.models.resnet18/34 with fc = Identity (classifier.py:36)."""
+class _Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck (v1.5: the stride sits on the 3x3 convolution), expansion 4."""
 
-    def __init__(self, layers):
+    def __init__(self, cin, width, stride):
+        super().__init__()
+        self.stride = stride
+        self.conv1 = _tv_conv(cin, width, 1)
+        self.bn1 = BNParams(width)
+        self.conv2 = _tv_conv(width, width, 3)
+        self.bn2 = BNParams(width)
+        self.conv3 = _tv_conv(width, 4 * width, 1)
+        self.bn3 = BNParams(4 * width)
+        if stride != 1 or cin != 4 * width:
+            self.downsample = Seq([(0, _tv_conv(cin, 4 * width, 1)), (1, BNParams(4 * width))])
+        else:
+            self.downsample = None
+
+    def run(self, eng: Engine, x: Act, tr: bool) -> Act:
+        h = eng.conv(x, self.conv1.weight, None, self.bn1.state(), k=1, stride=1, pad=0, relu=True, training=tr)
+        h = eng.conv(h, self.conv2.weight, None, self.bn2.state(), k=3, stride=self.stride, pad=1, relu=True, training=tr)
+        idt = x
+        if self.downsample is not None:
+            idt = eng.conv(x, self.downsample.at(0).weight, None, self.downsample.at(1).state(), k=1, stride=self.stride,
+                           pad=0, relu=False, training=tr)
+        return eng.conv(h, self.conv3.weight, None, self.bn3.state(), k=1, stride=1, pad=0, relu=True, residual=idt, training=tr)
+
+
+class _ResNet(nn.Module):
+    """torchvision.models.resnet18 / 34 (BasicBlock) / 50 (Bottleneck) with fc = Identity (classifier.py:24-36)."""
+
+    def __init__(self, layers, bottleneck: bool = False):
         super().__init__()
         self.conv1 = _tv_conv(3, 64, 7)
         self.bn1 = BNParams(64)
@@ -80,19 +108,24 @@ class _ResNet(nn.Module):
         for li, (c, n) in enumerate(zip((64, 128, 256, 512), layers), start=1):
             blocks = []
             for bi in range(n):
-                blocks.append((bi, _BasicBlock(cin, c, 2 if (bi == 0 and li > 1) else 1)))
-                cin = c
+                stride = 2 if (bi == 0 and li > 1) else 1
+                blocks.append((bi, _Bottleneck(cin, c, stride) if bottleneck else _BasicBlock(cin, c, stride)))
+                cin = 4 * c if bottleneck else c
             setattr(self, f"layer{li}", Seq(blocks))
         self.nlayers = layers
+        self.out_channels = cin
 
-    def run(self, eng: Engine, x8: Act, tr: bool) -> Act:
+    def feature_map(self, eng: Engine, x8: Act, tr: bool) -> Act:
         h = eng.conv(x8, self.conv1.weight, None, self.bn1.state(), k=7, stride=2, pad=3, relu=True, training=tr)
         h = eng.maxpool(h, 3, 2, 1)
         for li, n in enumerate(self.nlayers, start=1):
             layer = getattr(self, f"layer{li}")
             for bi in range(n):
                 h = layer.at(bi).run(eng, h, tr)
-        return eng.global_avgpool(h)
+        return h
+
+    def run(self, eng: Engine, x8: Act, tr: bool) -> Act:
+        return eng.global_avgpool(self.feature_map(eng, x8, tr))
 
 
 class _DenseLayer(nn.Module):
@@ -214,6 +247,8 @@ class FogIntensityClassifier(nn.Module):
                 self.backbone, self.feature_dim = _ResNet((2, 2, 2, 2)), 512
             elif model_name == "resnet34":
                 self.backbone, self.feature_dim = _ResNet((3, 4, 6, 3)), 512
+            elif model_name == "resnet50":
+                self.backbone, self.feature_dim = _ResNet((3, 4, 6, 3), bottleneck=True), 2048
             else:
                 raise ValueError(f"Unsupported ResNet variant: {model_name}")
         elif model_name == "densenet121":
@@ -261,6 +296,47 @@ class FogIntensityClassifier(nn.Module):
         with torch.no_grad():
             _, feats = self.forward(x)
         return feats
+
+
+class DenseFeatureExtractor(nn.Module):
+    """Extract dense feature maps from the backbone (classifier.py:105-137): torchvision's resnet18 / resnet34 without the
+    average pool and fc -- `nn.Sequential(*children[:-2])`, so the state_dict keys are `backbone.0.weight` (conv1),
+    `backbone.1.*` (bn1), `backbone.{4,5,6,7}.<block>.*` (layer1 .. layer4).  forward(x [N,3,H,W]) -> [N, 512, H/32, W/32].  The
+    reference's own drivers never use it; here it is the inference path (BatchNorm in the module's train / eval mode, no
+    gradients -- a training use would go through FogIntensityClassifier's autograd function).  mobilenet_v2 / efficientnet* need
+    torchvision / timm and raise ValueError like any unknown name."""
+
+    def __init__(self, model_name="resnet18", pretrained=True):
+        super().__init__()
+        if model_name == "resnet18":
+            net = _ResNet((2, 2, 2, 2))
+        elif model_name == "resnet34":
+            net = _ResNet((3, 4, 6, 3))
+        else:
+            raise ValueError(f"Unsupported model for feature extraction: {model_name}")
+        self.model_name = model_name
+        self._nlayers = net.nlayers
+        self.backbone = Seq([(0, net.conv1), (1, net.bn1), (4, net.layer1), (5, net.layer2), (6, net.layer3), (7, net.layer4)])
+        if pretrained:
+            warnings.warn("pretrained backbone weights cannot be downloaded in this environment; using torchvision's "
+                          "random initialisation (load a checkpoint with load_state_dict)")
+
+    @torch.no_grad()
+    def forward(self, x):
+        """Extract dense feature maps"""
+        H.require_cuda(x, "input image batch")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f"expected [N,3,H,W] input, got {tuple(x.shape)}")
+        eng = Engine(x.device, record=False)
+        tr = self.training
+        b = self.backbone
+        h = eng.conv(eng.image_to_nhwc8(x.contiguous()), b.at(0).weight, None, b.at(1).state(), k=7, stride=2, pad=3, relu=True,
+                     training=tr)
+        h = eng.maxpool(h, 3, 2, 1)
+        for idx, n in zip((4, 5, 6, 7), self._nlayers):
+            for bi in range(n):
+                h = b.at(idx).at(bi).run(eng, h, tr)
+        return h.t[..., :h.C].permute(0, 3, 1, 2).contiguous()
 
 
 def create_classifier(config):

@@ -16,7 +16,13 @@ def main():
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("ADH_DDP_BACKEND", "gloo")     # "nccl" = RCCL: one GPU per rank (needs >= world GPUs)
+    gpu = rank if backend == "nccl" else 0
+    if backend == "nccl":
+        torch.cuda.set_device(gpu)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import adam_dehaze_amd as A
     from adam_dehaze_amd.loss import l1_loss
     from adam_dehaze_amd.optim import Adam
@@ -24,7 +30,7 @@ def main():
     from adam_dehaze_amd.train import ReduceLROnPlateau
     from oracle import ref_cpu as R          # test infrastructure: only its synthetic_batch (the shared input recipe)
 
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", gpu)
     torch.cuda.set_device(dev)
     torch.manual_seed(100 + rank)            # replicas start DIFFERENT: the broadcast must fix that
     model = A.HighIntensityDehazeModel(base_channels=16).to(dev).train()
@@ -42,6 +48,8 @@ def main():
     import adam_dehaze_amd.engine as E
     for step in range(3):
         opt.zero_grad()
+        if step == 1:
+            sync.begin_selfcheck()              # (the bucket layout is rebuilt in step 0: the step after is the one checked)
         sync.begin_step()
         if step == 0:
             E.RELU_CAPTURE = {}
@@ -64,6 +72,8 @@ def main():
             rec["loss"] = float(loss)
             rec["out"] = out.detach().cpu().clone()
         opt.step()
+        if step == 1:
+            rec["selfcheck"] = sync.selfcheck_result(params)
         # rank-dependent raw metric (rank 0 improves, rank 1 gets worse): only the rank-mean may drive the scheduler
         raw = (1.0 - 0.3 * step) if rank == 0 else (1.0 + 0.5 * step)
         sched.step(all_reduce_mean_scalar(raw, dev))

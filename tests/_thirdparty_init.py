@@ -50,6 +50,44 @@ def resnet18_sd(seed=0):
     return sd
 
 
+def resnet50_sd(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    _conv(sd, "backbone.conv1", 64, 3, 7, g)
+    _bn(sd, "backbone.bn1", 64, g)
+    cin = 64
+    for li, (c, nb) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3)), start=1):
+        for bi in range(nb):
+            q = f"backbone.layer{li}.{bi}"
+            _conv(sd, q + ".conv1", c, cin, 1, g)
+            _bn(sd, q + ".bn1", c, g)
+            _conv(sd, q + ".conv2", c, c, 3, g)
+            _bn(sd, q + ".bn2", c, g)
+            _conv(sd, q + ".conv3", 4 * c, c, 1, g)
+            _bn(sd, q + ".bn3", 4 * c, g)
+            sd[q + ".bn3.weight"] *= 0.5       # keeps the residual sums of 16 random-weight blocks from growing
+            if bi == 0:
+                _conv(sd, q + ".downsample.0", 4 * c, cin, 1, g)
+                _bn(sd, q + ".downsample.1", 4 * c, g)
+            cin = 4 * c
+    _head(sd, 2048, g)
+    return sd
+
+
+def resnet18_feature_extractor_sd(seed=0):
+    """DenseFeatureExtractor('resnet18') keys: the classifier's resnet18 backbone renumbered as nn.Sequential children."""
+    src = resnet18_sd(seed)
+    ren = {"conv1": "0", "bn1": "1", "layer1": "4", "layer2": "5", "layer3": "6", "layer4": "7"}
+    out = {}
+    for k, v in src.items():
+        if not k.startswith("backbone."):
+            continue
+        parts = k.split(".")
+        parts[1] = ren[parts[1]]
+        out[".".join(parts)] = v
+    return out
+
+
 def densenet121_sd(seed=0):
     g = torch.Generator().manual_seed(seed)
     sd = {}

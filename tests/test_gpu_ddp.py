@@ -39,9 +39,21 @@ def _run_ranks(tmp_path, world, port_base, **extra_env):
     return [torch.load(tmp_path / f"rank{r}.pt", map_location="cpu") for r in range(world)]
 
 
-def test_two_rank_training_step_matches_shardwise_oracle(tmp_path):
+BACKENDS = [pytest.param("gloo", id="gloo-one-gpu"),
+            # RCCL over xGMI, one GPU per rank: runs wherever the box has two GPUs (the one-GPU test box skips it; the nccl
+            # branches of parallel.py -- ReduceOp.AVG, bucket all-reduces launched from inside backward onto RCCL's stream,
+            # the sync-BN all-reduce on RCCL's stream -- are otherwise only rehearsed under gloo)
+            pytest.param("nccl", id="rccl-two-gpus",
+                         marks=pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)"))]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_two_rank_training_step_matches_shardwise_oracle(tmp_path, backend):
     world = 2
-    recs = _run_ranks(tmp_path, world, 31000, ADH_WINOGRAD="0")   # direct kernels: reference summation order
+    recs = _run_ranks(tmp_path, world, 31000, ADH_WINOGRAD="0", ADH_DDP_BACKEND=backend)   # direct kernels: reference summation order
+    for r in range(world):       # the self-check bench.py prints as `ddp_selfcheck` (parallel.GradientSynchronizer.selfcheck_result)
+        sc = recs[r]["selfcheck"]
+        assert sc["ok"] and sc["backend"] == backend and sc["params_bit_equal"] and sc["max_rel"] < 1e-5, sc
     # replicas were seeded differently and broadcast from rank 0
     for k, v in recs[0]["sd0"].items():
         assert torch.equal(v, recs[1]["sd0"][k]), k
@@ -87,8 +99,9 @@ def test_two_rank_training_step_matches_shardwise_oracle(tmp_path):
     assert recs[0]["order"][1] == recs[1]["order"][1]
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("kernels", ["direct", "winograd"])
-def test_two_rank_sync_bn_matches_the_unsharded_reference(tmp_path, kernels):
+def test_two_rank_sync_bn_matches_the_unsharded_reference(tmp_path, kernels, backend):
     """SURVEY 8e mode (ii), VERDICT r2 item 7: with `GradientSynchronizer(sync_bn=True)` every train-mode BatchNorm layer
     all-reduces its [sum, sum of squares, count] (and [sum g, sum g*xhat] in the backward pass), so two ranks with two
     images each reproduce the SINGLE-PROCESS reference on the unsharded 4-image batch (/root/reference
@@ -97,7 +110,9 @@ def test_two_rank_sync_bn_matches_the_unsharded_reference(tmp_path, kernels):
     L1 loss with the ranks' own ReLU masks replayed (gate: 3 x the fp32 reference's own distance + 3e-4).  Run with the direct
     kernels and with the default Winograd kernels (the replica-BN test above pins ADH_WINOGRAD=0)."""
     world = 2
-    recs = _run_ranks(tmp_path, world, 33000, ADH_DDP_SYNC_BN="1", **({"ADH_WINOGRAD": "0"} if kernels == "direct" else {}))
+    recs = _run_ranks(tmp_path, world, 33000, ADH_DDP_SYNC_BN="1", ADH_DDP_BACKEND=backend,
+                      **({"ADH_WINOGRAD": "0"} if kernels == "direct" else {}))
+    assert all(recs[r]["selfcheck"]["ok"] for r in range(world)), [recs[r]["selfcheck"] for r in range(world)]
     hazy, clear, _ = R.synthetic_batch(2 * world, 32, 48, seed=77)
     masks = {k: torch.cat([recs[r]["masks"][k] for r in range(world)], dim=0) for k in recs[0]["masks"]}
 

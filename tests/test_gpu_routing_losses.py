@@ -15,7 +15,7 @@ from adam_dehaze_amd import loss as L
 from adam_dehaze_amd import routing as RT
 from adam_dehaze_amd.optim import Adam
 from oracle import ref_cpu as R
-from tests._thirdparty_init import densenet121_sd, lpips_alex_sd, resnet18_sd, vgg16_sd
+from tests._thirdparty_init import densenet121_sd, lpips_alex_sd, resnet18_feature_extractor_sd, resnet18_sd, resnet50_sd, vgg16_sd
 from tests._util import load_golden, max_abs, rel_err, sub_sd, t
 
 pytestmark = pytest.mark.gpu
@@ -145,7 +145,7 @@ def test_adam_duplicate_param_step_vs_reference_fixture():
         assert max_abs(ws, rec[f"w_single{step + 1}"]) < 2e-7
 
 
-@pytest.mark.parametrize("name,sdfn,fd", [("resnet18", resnet18_sd, 512), ("densenet121", densenet121_sd, 1024)])
+@pytest.mark.parametrize("name,sdfn,fd", [("resnet18", resnet18_sd, 512), ("resnet50", resnet50_sd, 2048), ("densenet121", densenet121_sd, 1024)])
 def test_classifier_forward_vs_oracle(name, sdfn, fd):
     sd = sdfn(3)
     with warnings.catch_warnings():
@@ -216,6 +216,71 @@ def test_resnet18_classifier_train_backward_vs_oracle():
               "backbone.conv1.weight", "backbone.layer1.0.bn1.weight"):
         ref = sdr[k].grad
         assert rel_err(names[k].grad, ref) < 2e-2, k
+
+
+def test_resnet50_classifier_train_backward_and_dense_feature_extractor():
+    """VERDICT r3 missing 1 / 2 (/root/reference models/classifier.py:31-33,105-137).  (i) The resnet50 HDEN trains: train-mode
+    BatchNorm + backward through the Bottleneck stack against a float64 torch restatement of the same graph (dropout masks of
+    ones), selected gradients within 2e-2 of their scale (the BasicBlock test's gate).  (ii) DenseFeatureExtractor('resnet18')
+    loads a torchvision-keyed state_dict strictly and returns the [N, 512, H/32, W/32] map of the oracle; unsupported names
+    raise ValueError as in the reference."""
+    sd = resnet50_sd(4)
+    m = CL.FogIntensityClassifier("resnet50", 3, pretrained=False)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    hazy, _, labels = R.synthetic_batch(4, 64, 96, seed=6)
+    ones = (torch.ones(4, 1, 1, 2048, device=DEV), torch.ones(4, 1, 1, 256, device=DEV))
+    logits, feats = CL._ClassifierFunction.apply(m, True, hazy.to(DEV).contiguous(), ones, *list(m.parameters()))
+    loss = L.cross_entropy3(logits, labels.to(DEV))
+    loss.backward()
+    sdr = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    for k, v in sdr.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+
+    def bn(x, p):
+        return F.batch_norm(x, sdr[p + "running_mean"], sdr[p + "running_var"], sdr[p + "weight"], sdr[p + "bias"],
+                            training=True, momentum=0.1, eps=1e-5)
+    h = F.relu(bn(F.conv2d(hazy.double(), sdr["backbone.conv1.weight"], None, 2, 3), "backbone.bn1."))
+    h = F.max_pool2d(h, 3, 2, 1)
+    for li, nb in enumerate((3, 4, 6, 3), start=1):
+        for bi in range(nb):
+            q = f"backbone.layer{li}.{bi}."
+            s = 2 if (li > 1 and bi == 0) else 1
+            idt = h
+            o = F.relu(bn(F.conv2d(h, sdr[q + "conv1.weight"]), q + "bn1."))
+            o = F.relu(bn(F.conv2d(o, sdr[q + "conv2.weight"], None, s, 1), q + "bn2."))
+            o = bn(F.conv2d(o, sdr[q + "conv3.weight"]), q + "bn3.")
+            if q + "downsample.0.weight" in sdr:
+                idt = bn(F.conv2d(h, sdr[q + "downsample.0.weight"], None, s), q + "downsample.1.")
+            h = F.relu(o + idt)
+    f = torch.flatten(F.adaptive_avg_pool2d(h, 1), 1)
+    ref_logits = R.classifier_head(f, sdr)
+    ref_loss = F.cross_entropy(ref_logits, labels)
+    ref_loss.backward()
+    assert max_abs(logits, ref_logits.detach()) < 2e-3 * max(1.0, float(ref_logits.abs().max()))
+    assert abs(float(loss) - float(ref_loss)) < 1e-3
+    names = dict(m.named_parameters())
+    for k in ("classifier.4.weight", "classifier.1.weight", "backbone.layer4.2.conv3.weight", "backbone.layer3.0.downsample.0.weight",
+              "backbone.layer2.1.conv2.weight", "backbone.conv1.weight", "backbone.layer1.0.bn3.weight"):
+        assert rel_err(names[k].grad, sdr[k].grad) < 2e-2, k
+    # (ii)
+    fsd = resnet18_feature_extractor_sd(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fx = CL.DenseFeatureExtractor("resnet18", pretrained=True)
+    fx.load_state_dict(fsd, strict=True)
+    fx = fx.to(DEV).eval()
+    x, _, _ = R.synthetic_batch(2, 96, 160, seed=8)
+    got = fx(x.to(DEV))
+    with torch.no_grad():
+        want = R.resnet_feature_map(x, fsd)
+    assert got.shape == (2, 512, 3, 5) == want.shape
+    assert rel_err(got, want) < 1e-3
+    with pytest.raises(ValueError, match="feature extraction"):
+        CL.DenseFeatureExtractor("mobilenet_v2", pretrained=False)
+    import models.classifier as MC
+    assert MC.DenseFeatureExtractor is CL.DenseFeatureExtractor
 
 
 def test_losses_vs_oracle():
