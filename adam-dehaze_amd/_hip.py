@@ -74,6 +74,9 @@ _SIGNATURES = {
     "adh_conv_wino32_forward": [vp, PD],
     "adh_conv_wino32_forward_multi": [vp, PD, i32],
     "adh_pack_weights_wino32": [vp, vp, PL, vp],
+    "adh_conv_wino32_forward_bf16x3": [vp, PD],
+    "adh_conv_wino32_forward_multi_bf16x3": [vp, PD, i32],
+    "adh_pack_weights_wino32_bf16x3": [vp, vp, PL, vp],
     "adh_conv_wino43_supported": [PD],
     "adh_conv_wino43_num_blocks": [PD],
     "adh_conv_wino43_forward": [vp, PD],

@@ -36,6 +36,8 @@
 #endif
 #include <cstdlib>
 #include <cstring>
+#define B3_NO_SPLIT ((W3_DBG & 16) != 0)
+#include "bf16x3.h"
 
 #define W2_KC 16
 #define W2_TILES 64
@@ -549,6 +551,153 @@ extern "C" int adh_w3_prof_read(void* dst) {
 #define W3_STAMP(i) do {} while (0)
 #endif
 
+// ------------------------------------------------------------------------------------------------ bf16 x 3 contraction of
+// conv_wino32_kernel (round 4, opt-in: adh_conv_wino32_forward_bf16x3; the scheme of conv_wino43.hip / bf16x3.h).  This kernel
+// suits it better than the F(4x4,3x3) one: a wave holds TWO 32-tile row blocks per frequency (8 NT accumulator tiles), so every
+// weight register feeds twice the MFMAs (0.25 weight loads per MFMA), 8 NT tiles leave 128 registers for the planes in the making,
+// and the contraction is 84 % of a slab.  Per slab and wave: frequencies fi = 0 .. 3, groups G = fi NT + j of 12 MFMAs (both
+// row blocks x six plane pairs) on 3 weight registers requested two groups ahead; the planes of frequency fi + 1 (two sets of
+// eight values) are split in the gaps of frequency fi.  The staging pieces of the next slab (10 per wave) ride behind the first
+// MFMA of the groups from 1 on.
+template <int NT>
+constexpr int w3b_pieces(int G) {   // pieces issued in group G
+    if (W3_DBG & 8) return 0;
+    if (G < 1) return 0;
+    constexpr int ng = 4 * NT - 1;                       // groups 1 .. 4 NT - 1 may carry pieces
+    constexpr int per = (10 + ng - 2) / (ng - 1);        // leave the last group free
+    const int first = (G - 1) * per;
+    return first >= 10 ? 0 : (10 - first < per ? 10 - first : per);
+}
+template <int NT>
+constexpr int w3b_piece0(int G) { return (G - 1) * ((10 + 4 * NT - 3) / (4 * NT - 2)); }
+template <int NM, int M, int S = 0>
+constexpr int w3b_first_step() {   // first of the 40 steps (two sets of 20) whose gap is >= M; steps run from gap 3 to gap NM - 1
+    if constexpr (S >= 40) return 40;
+    else if constexpr (3 + S * (NM - 3) / 40 >= M) return S;
+    else return w3b_first_step<NM, M, S + 1>();
+}
+template <int S0, int S1>
+__device__ __forceinline__ void w3b_steps(W4BNext (&n)[2], float m1) {   // step s < 20: set 0, else set 1
+    if constexpr (S0 < S1) {
+        w4b_step<S0 % 20>(n[S0 / 20], m1);
+        w3b_steps<S0 + 1, S1>(n, m1);
+    }
+}
+__device__ __forceinline__ void w3b_load_s(W4BNext (&n)[2], const float* p0, const float* p1) {
+    // p0 / p1: the lane's channel quads h and 2 + h of tile l31; + 512 floats = tile l31 + 32 (the second row block)
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p0 + th * 512), b = *reinterpret_cast<const f32x4*>(p1 + th * 512);
+        n[th].s[0] = a[0]; n[th].s[1] = a[1]; n[th].s[2] = a[2]; n[th].s[3] = a[3];
+        n[th].s[4] = b[0]; n[th].s[5] = b[1]; n[th].s[6] = b[2]; n[th].s[7] = b[3];
+    }
+}
+template <int NT, int FI, int M>
+__device__ __forceinline__ void w3b_gap(W4BNext (&n)[2], const float* v0, const float* v1, float m1) {
+    constexpr int NM = 12 * NT;
+    if constexpr (FI + 1 < 4) {
+        w3b_steps<w3b_first_step<NM, M>(), w3b_first_step<NM, M + 1>()>(n, m1);
+        if constexpr (M == NM - 1 && FI + 2 < 4) w3b_load_s(n, v0 + (FI + 2) * 1024, v1 + (FI + 2) * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+struct W3Slab { int iy0, ix0, cb, so0; bool interior; };   // wave-uniform geometry of one slab's halo
+struct W3Stage {            // what issuing staging pieces needs, as plain data (a callable cannot be passed into a function template
+    __amdgpu_buffer_rsrc_t xr;   // from a __global__ template: hipcc's host pass then drops the kernel's stub)
+    float* rawbase;
+    int vfull, vtail, wave, px_l, cq_l, xps, IH, IW, in_cstride, xcs, xrs;
+};
+// pieces u0 .. u1 - 1 of the ten this wave stages per slab into raw buffer `buf` (the body of conv_wino32_kernel's stage_raw)
+__device__ __forceinline__ void w3b_stage(const W3Stage& st, const W3Slab& sg, int buf, int u0, int u1) {
+    float* raw = st.rawbase + buf * W3_RAW_F;
+    int wv = st.wave;
+    asm volatile("" : "+s"(wv));
+    if (sg.interior) {
+        for (int u = u0; u < u1; ++u) {
+            const int j = 4 * u + wv;
+            if (j < 39) {
+                const int r = (j * 171) >> 9, p = j - r * 3;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xr, (lds_void_ptr)(raw + r * W3_RAW_PITCH + p * 256), 16, st.vfull,
+                                                         __builtin_amdgcn_readfirstlane(sg.so0 + r * st.xrs + p * st.xcs), 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xr, (lds_void_ptr)(raw + W3_RAW_ROWS * W3_RAW_PITCH), 16, st.vtail,
+                                                         __builtin_amdgcn_readfirstlane(sg.so0), 0, 0);
+            }
+        }
+    } else {
+        for (int u = u0; u < u1; ++u) {
+            const int j = 4 * u + wv;
+            const bool tail = j >= 39;
+            const int rs = (j * 171) >> 9, p = tail ? 0 : j - rs * 3;
+            const int r = tail ? (st.px_l < W3_RAW_ROWS ? st.px_l : 0) : rs;
+            const int col = tail ? 48 : 3 * st.px_l + p;
+            const int iy = adh_min_i(adh_max_i(sg.iy0 + r * st.xps, 0), st.IH - 1);
+            const int ix = adh_min_i(adh_max_i(sg.ix0 + col * st.xps, 0), st.IW - 1);
+            const int vo = (iy * st.IW + ix) * st.in_cstride * 4 + st.cq_l * 16;
+            const int doff = __builtin_amdgcn_readfirstlane(tail ? W3_RAW_ROWS * W3_RAW_PITCH : rs * W3_RAW_PITCH + p * 256);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xr, (lds_void_ptr)(raw + doff), 16, vo, __builtin_amdgcn_readfirstlane(sg.cb), 0, 0);
+        }
+    }
+}
+// groups G .. 4 NT - 1 of one slab (see above); a[th][plane] = the planes of the current frequency for the two row blocks
+template <int NT, int G>
+__device__ __forceinline__ void w3b_groups(f32x16 (&acc)[8 * NT], u32x4 (&a)[2][3], W4BNext (&n)[2], u32x4 (&bv)[3][3], const float* v0,
+                                           const float* v1, unsigned b_voff, const char* b_slab, float m1, const W3Stage& st,
+                                           const W3Slab& sgn, int nbuf) {
+    if constexpr (G < 4 * NT) {
+        constexpr int FI = G / NT, J = G % NT, G2 = G + 2;
+        if constexpr (G2 < 4 * NT) w4b_load_b(bv[G2 % 3], b_voff, b_slab + G2 * 3072);
+        constexpr int newer = 3 * (4 * NT - 1 - G < 2 ? 4 * NT - 1 - G : 2) + w3b_pieces<NT>(G - 2) + w3b_pieces<NT>(G - 1);
+        u32x4(&b)[3] = bv[G % 3];
+        w4b_wait_b<newer>(b);
+        constexpr bool ag0 = w2_in_agpr<NT, FI * 2 + 0, J>(), ag1 = w2_in_agpr<NT, FI * 2 + 1, J>();
+        f32x16& c0 = acc[(FI * 2 + 0) * NT + J];
+        f32x16& c1 = acc[(FI * 2 + 1) * NT + J];
+        w4b_mfma<ag0>(c0, a[0][0], b[0]);
+        if constexpr (w3b_pieces<NT>(G) > 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            w3b_stage(st, sgn, nbuf, w3b_piece0<NT>(G), w3b_piece0<NT>(G) + w3b_pieces<NT>(G));
+        }
+        w3b_gap<NT, FI, 12 * J + 1>(n, v0, v1, m1);
+        w4b_mfma<ag0>(c0, a[0][0], b[1]);
+        w3b_gap<NT, FI, 12 * J + 2>(n, v0, v1, m1);
+        w4b_mfma<ag0>(c0, a[0][0], b[2]);
+        w3b_gap<NT, FI, 12 * J + 3>(n, v0, v1, m1);
+        w4b_mfma<ag0>(c0, a[0][1], b[0]);
+        w3b_gap<NT, FI, 12 * J + 4>(n, v0, v1, m1);
+        w4b_mfma<ag0>(c0, a[0][1], b[1]);
+        w3b_gap<NT, FI, 12 * J + 5>(n, v0, v1, m1);
+        w4b_mfma<ag0>(c0, a[0][2], b[0]);
+        w3b_gap<NT, FI, 12 * J + 6>(n, v0, v1, m1);
+        w4b_mfma<ag1>(c1, a[1][0], b[0]);
+        w3b_gap<NT, FI, 12 * J + 7>(n, v0, v1, m1);
+        w4b_mfma<ag1>(c1, a[1][0], b[1]);
+        w3b_gap<NT, FI, 12 * J + 8>(n, v0, v1, m1);
+        w4b_mfma<ag1>(c1, a[1][0], b[2]);
+        w3b_gap<NT, FI, 12 * J + 9>(n, v0, v1, m1);
+        w4b_mfma<ag1>(c1, a[1][1], b[0]);
+        w3b_gap<NT, FI, 12 * J + 10>(n, v0, v1, m1);
+        w4b_mfma<ag1>(c1, a[1][1], b[1]);
+        w3b_gap<NT, FI, 12 * J + 11>(n, v0, v1, m1);
+        w4b_mfma<ag1>(c1, a[1][2], b[0]);
+        if constexpr (J == NT - 1 && FI + 1 < 4) {
+            // hand-over to frequency FI + 1 (planes written by VALU instructions at least one MFMA ago; the s_nop covers a register
+            // copy landing here: hipcc's hazard recogniser does not look into the MFMA statements)
+#pragma unroll
+            for (int th = 0; th < 2; ++th) {
+                a[th][0] = u32x4{n[th].h[0], n[th].h[1], n[th].h[2], n[th].h[3]};
+                a[th][1] = u32x4{n[th].m[0], n[th].m[1], n[th].m[2], n[th].m[3]};
+                a[th][2] = u32x4{n[th].l[0], n[th].l[1], n[th].l[2], n[th].l[3]};
+            }
+            asm volatile("s_nop 1" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]));
+        } else {
+            w3b_gap<NT, FI, 12 * J + 12>(n, v0, v1, m1);
+        }
+        w3b_groups<NT, G + 1>(acc, a, n, bv, v0, v1, b_voff, b_slab, m1, st, sgn, nbuf);
+    }
+}
+
 struct Wino32Geom {
     int tiles_x, tiles_y;        // 48-col x 12-row regions of virtual pixels
     int nregions;
@@ -566,7 +715,7 @@ struct Wino32Geom {
     float* m_stats[4];
 };
 
-template <int NT>
+template <int NT, bool BF3 = false>
 __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc d, const Wino32Geom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // V[16][64][16] | raw[2][13][768]+tail | red
     float* const rawbase = lds + W2_VBUF_F;
@@ -617,7 +766,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     // pieces u0 .. u1-1 of the 10 this wave stages per slab (the whole tile in the prologue, two per contraction group later)
     const int vfull = 3 * px_l * xcs + cq_l * 16;
     const int vtail = (px_l < W3_RAW_ROWS ? px_l : 0) * xrs + 48 * xcs + cq_l * 16;
-    struct SlabGeom { int iy0, ix0, cb, so0; bool interior; };   // wave-uniform, computed once per slab
+    typedef W3Slab SlabGeom;   // wave-uniform, computed once per slab
     auto slab_geom = [&](int slab) {
         SlabGeom sg;
         const int chunk = slab / g.ncls, c = slab - chunk * g.ncls;
@@ -670,17 +819,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
         if (iy0 >= 0 && iy0 + 12 * g.xps < d.IH && ix0 >= 0 && ix0 + 48 * g.xps < d.IW) return;
         float* raw = rawbase + buf * W3_RAW_F;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        // bf16 x 3 form: the per-lane geometry is rebuilt from v_mbcnt here -- hoisted out of the slab loop (as hipcc does with
+        // lane-derived values) it would sit in registers the contraction has no room for, i.e. in scratch
+        int ln = lane;
+        if constexpr (BF3) {
+            ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(ln));
+        }
+        const int pxl = ln >> 2;
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
             const int j = 4 * u + wave;
             const bool tail = j >= 39;
-            const int r = tail ? px_l : ((j * 171) >> 9);
+            const int r = tail ? pxl : ((j * 171) >> 9);
             const int p = tail ? 0 : j - ((j * 171) >> 9) * 3;
-            const int col = tail ? 48 : 3 * px_l + p;
+            const int col = tail ? 48 : 3 * pxl + p;
             const int iy = iy0 + r * g.xps, ix = ix0 + col * g.xps;
             const bool ok = iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
-            float* dst = (tail ? raw + W3_RAW_ROWS * W3_RAW_PITCH : raw + r * W3_RAW_PITCH + p * 256) + lane * 4;
-            if (!ok && (!tail || px_l < W3_RAW_ROWS)) *reinterpret_cast<f32x4*>(dst) = z;
+            float* dst = (tail ? raw + W3_RAW_ROWS * W3_RAW_PITCH : raw + r * W3_RAW_PITCH + p * 256) + ln * 4;
+            if (!ok && (!tail || pxl < W3_RAW_ROWS)) *reinterpret_cast<f32x4*>(dst) = z;
         }
     };
 
@@ -731,6 +888,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // bf16 x 3 form: A = the same reads, split in registers; B = adh_pack_weights_wino32_bf16x3's
+    // [class][channel group][chunk][16 f][NT][3 planes][64 lanes][16 B]: the 4 NT groups of a wave and slab are 12 NT KB contiguous
+    const float* const v0 = lds + a_lane;
+    const float* const v1 = lds + (a_lane ^ 8);
+    const unsigned b3_voff = (unsigned)lane * 16u;
+    const size_t b3_chunk = (size_t)16 * NT * 3072, b3_cls = (size_t)g.ncog * g.nchunks * b3_chunk;
+    const char* const b3_wave = reinterpret_cast<const char*>(wp_m) + ((size_t)cg * g.nchunks * 16 + (size_t)wave * 4) * (NT * 3072);
+    auto b3_ptr = [&](int slab) {
+        const int chunk = slab / g.ncls, c = slab - chunk * g.ncls;
+        return b3_wave + (size_t)c * b3_cls + (size_t)chunk * b3_chunk;
+    };
+    W3Stage st3;
+    st3.xr = xr; st3.rawbase = rawbase; st3.vfull = vfull; st3.vtail = vtail; st3.wave = wave; st3.px_l = px_l; st3.cq_l = cq_l;
+    st3.xps = g.xps; st3.IH = d.IH; st3.IW = d.IW; st3.in_cstride = d.in_cstride; st3.xcs = xcs; st3.xrs = xrs;
+    u32x4 av3[2][3], bv3[3][3];
+    W4BNext nx[2];
+    const float m1s = adh_opaque(-1.f);
+
     f32x4 av[2][2], bv[2][NT];
     auto load_a = [&](int f, int gg, f32x4 (&a)[2]) {
         const float* p = lds + f * 1024 + (gg ? (a_lane ^ 8) : a_lane);
@@ -744,7 +919,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
 
     // ------------------------------------------------------------------ prologue
     const int nslabs = g.nchunks * g.ncls;
-    w2_load_b<NT>(bv[0], b_voff, b_ptr(0, 0, 0));
+    if constexpr (!BF3) w2_load_b<NT>(bv[0], b_voff, b_ptr(0, 0, 0));
     stage_raw(slab_geom(0), 0, 0, 10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fix_raw(0, 0);
@@ -766,7 +941,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
         const int sn = s + 1 < nslabs ? s + 1 : s;     // the last slab re-stages itself: uniform counts
         constexpr int P = (W3_DBG & 8) ? 0 : 2;
         const SlabGeom sgn = slab_geom(sn);
-        if (!(W3_DBG & 2)) {
+        if constexpr (BF3) {
+            if (!(W3_DBG & 2)) {
+                // the weights of groups 0 and 1 are requested HERE, not behind the previous slab's transform: a register an asm load is
+                // still filling must not be carried over the loop's back edge (hipcc resolves the carry with register copies that run
+                // before the load has landed: conv_wino43.hip, w4b_groups); the planes of the wave's first frequency are split while
+                // they are on their way; then the values of the second frequency are requested
+                w4b_load_b(bv3[0], b3_voff, b3_ptr(s));
+                w4b_load_b(bv3[1], b3_voff, b3_ptr(s) + 3072);
+                w3b_load_s(nx, v0, v1);
+                w3b_steps<0, 40>(nx, m1s);
+#pragma unroll
+                for (int th = 0; th < 2; ++th) {
+                    av3[th][0] = u32x4{nx[th].h[0], nx[th].h[1], nx[th].h[2], nx[th].h[3]};
+                    av3[th][1] = u32x4{nx[th].m[0], nx[th].m[1], nx[th].m[2], nx[th].m[3]};
+                    av3[th][2] = u32x4{nx[th].l[0], nx[th].l[1], nx[th].l[2], nx[th].l[3]};
+                }
+                asm volatile("s_nop 1" : "+v"(av3[0][0]), "+v"(av3[0][1]), "+v"(av3[0][2]), "+v"(av3[1][0]), "+v"(av3[1][1]), "+v"(av3[1][2]));
+                w3b_load_s(nx, v0 + 1024, v1 + 1024);
+                __builtin_amdgcn_sched_barrier(0);
+                w3b_groups<NT, 0>(acc, av3, nx, bv3, v0, v1, b3_voff, b3_ptr(s), m1s, st3, sgn, (s + 1) & 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last pieces (issued at least two groups ago) have landed
+            }
+        } else if (!(W3_DBG & 2)) {
         load_a(0, 0, av[0]);
         w2_load_b<NT>(bv[1], b_voff, b_ptr(s, 1, 0));
         load_a(1, 0, av[1]);
@@ -827,7 +1024,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
         __builtin_amdgcn_s_barrier();
         if (s == 1) W3_STAMP(12);
     }
-    w2_wait_b<0, NT>(bv[0]);
+    if constexpr (!BF3) w2_wait_b<0, NT>(bv[0]);
     W3_STAMP(2);
 
     if (W3_DBG & 4) return;
@@ -1018,17 +1215,17 @@ extern "C" int adh_conv_wino32_num_blocks(const adh_conv_desc* d) {
     return g.nregions;
 }
 
-template <int NT>
+template <int NT, bool BF3 = false>
 static int launch_wino32(hipStream_t s, const adh_conv_desc* d, Wino32Geom g) {
     g.ncog = d->NcP / (32 * NT);
     const int nblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<NT, BF3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_wino32_kernel<NT>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, *d, g);
+    hipLaunchKernelGGL((conv_wino32_kernel<NT, BF3>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, *d, g);
     return adh_check_launch();
 }
 
-extern "C" int adh_conv_wino32_forward(void* stream, const adh_conv_desc* d) {
+static int wino32_forward_impl(void* stream, const adh_conv_desc* d, bool bf3) {
     Wino32Geom g;
     if (!wino32_plan(d, &g)) return ADH_E_UNSUPPORTED;
     if (!d->in || !d->out || !d->wp || d->NcP < d->Cout) return ADH_E_ARG;
@@ -1039,18 +1236,28 @@ extern "C" int adh_conv_wino32_forward(void* stream, const adh_conv_desc* d) {
     if (((uintptr_t)d->in & 15) || ((uintptr_t)d->wp & 15)) return ADH_E_ARG;
     const int nt = d->NcP / 32;
     hipStream_t s = (hipStream_t)stream;
+    if (bf3) {
+        if (nt % 3 == 0) return launch_wino32<3, true>(s, d, g);
+        if (nt % 2 == 0) return launch_wino32<2, true>(s, d, g);
+        return launch_wino32<1, true>(s, d, g);
+    }
     if (nt % 3 == 0) return launch_wino32<3>(s, d, g);
     if (nt % 2 == 0) return launch_wino32<2>(s, d, g);
     return launch_wino32<1>(s, d, g);
 }
 
+extern "C" int adh_conv_wino32_forward(void* stream, const adh_conv_desc* d) { return wino32_forward_impl(stream, d, false); }
+// The same launch (and the merged form below) with the contraction on v_mfma_f32_32x32x16_bf16 over exact three-plane bf16 splits
+// of both operands (opt-in, ADH_CONTRACT=bf16x3; d->wp from adh_pack_weights_wino32_bf16x3): see the comment at w3b_pieces.
+extern "C" int adh_conv_wino32_forward_bf16x3(void* stream, const adh_conv_desc* d) { return wino32_forward_impl(stream, d, true); }
+
 // Several single-class launches of ONE layer as one grid: the output-parity classes of a transposed convolution / of the data
 // gradient of a k4 s2 convolution (2 x 2-tap forms).  Their grids are not multiples of the CU count (ConvTranspose 384 -> 192:
 // 1056 workgroups = 4.125 rounds of one workgroup per CU), so four launches waste up to four partial rounds; one grid wastes one.
 // The descriptors may differ in wp, out_oy / out_ox, dy0 / dx0 and stats only (checked); n = 2 .. 4.
-extern "C" int adh_conv_wino32_forward_multi(void* stream, const adh_conv_desc* descs, int n) {
+static int wino32_forward_multi_impl(void* stream, const adh_conv_desc* descs, int n, bool bf3) {
     if (!descs || n < 1 || n > 4) return ADH_E_ARG;
-    if (n == 1) return adh_conv_wino32_forward(stream, descs);
+    if (n == 1) return wino32_forward_impl(stream, descs, bf3);
     Wino32Geom g0;
     if (!wino32_plan(&descs[0], &g0) || g0.ncls != 1) return ADH_E_UNSUPPORTED;
     for (int m = 0; m < n; ++m) {
@@ -1082,6 +1289,19 @@ extern "C" int adh_conv_wino32_forward_multi(void* stream, const adh_conv_desc* 
     g0.mblocks = ((g0.nregions + 7) / 8) * g0.ncog * 8;
     const int nblocks = n * g0.mblocks;
     hipStream_t s = (hipStream_t)stream;
+    if (bf3) {
+        if (NT == 3) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((conv_wino32_kernel<3, true>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
+        } else if (NT == 2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((conv_wino32_kernel<2, true>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((conv_wino32_kernel<1, true>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
+        }
+        return adh_check_launch();
+    }
     if (NT == 3) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((conv_wino32_kernel<3>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
@@ -1093,6 +1313,13 @@ extern "C" int adh_conv_wino32_forward_multi(void* stream, const adh_conv_desc* 
         hipLaunchKernelGGL((conv_wino32_kernel<1>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
     }
     return adh_check_launch();
+}
+
+extern "C" int adh_conv_wino32_forward_multi(void* stream, const adh_conv_desc* descs, int n) {
+    return wino32_forward_multi_impl(stream, descs, n, false);
+}
+extern "C" int adh_conv_wino32_forward_multi_bf16x3(void* stream, const adh_conv_desc* descs, int n) {
+    return wino32_forward_multi_impl(stream, descs, n, true);
 }
 
 // U[cls][f = a*4+b][k/4][n][4] = (A g_cls A^T)[a][b], A = [[1,0],[1,1],[1,-1],[0,-1]]; g_cls[ty][tx] is tap
@@ -1155,6 +1382,86 @@ extern "C" int adh_pack_weights_wino32(void* stream, const float* src, const adh
     const int64_t total = (int64_t)ncls * KQ * NcP;
     hipLaunchKernelGGL(pack_weights_wino32_kernel, dim3(adh_min_i(adh_ceil_div(total, 128), 4096)), dim3(128), 0,
                        (hipStream_t)stream, src, *L, KQ, NcP, ncls, reinterpret_cast<f32x4*>(wp));
+    return adh_check_launch();
+}
+
+// The same U (the same fp32 sums and differences), split exactly into three bf16 planes and laid out for
+// conv_wino32_kernel<NT, true>: [class][channel group of 32 NT][chunk of 16 k][16 f][NT tiles][3 planes][half h][32 n][8 k] bf16
+// (the eight k of half h: channels 4h .. 4h+3 and 8+4h .. 8+4h+3 of the chunk), NT as the launch picks it from NcP.
+// wp: ncls * 16 * Kp * NcP * 6 bytes (Kp = K rounded up to 16, NcP = Nc rounded up to 32).
+__global__ void pack_weights_wino32_bf16x3_kernel(const float* __restrict__ src, const adh_wlayout L, int KO, int NcP, int ncls, int NT,
+                                                  u32x4* __restrict__ wp) {
+    const int64_t total = (int64_t)ncls * KO * NcP;
+    const int cstep = ncls == 4 ? 2 : 1;
+    const int nchunks = KO / 2, ncog = NcP / (32 * NT);
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % NcP);
+        int64_t r = idx / NcP;
+        const int ko = (int)(r % KO);
+        const int cls = (int)(r / KO);
+        const int cy = cls >> 1, cx = cls & 1;
+        const int cog = n / (32 * NT), j = (n >> 5) % NT, l31 = n & 31, chunk = ko >> 1, hh = ko & 1;
+        float u[16][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = chunk * 16 + (i < 4 ? 4 * hh + i : 8 + 4 * hh + (i - 4));
+            float gg[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    gg[a][b] = (n < L.Nc && k < L.K)
+                                   ? src[(int64_t)L.tap_off0 + (a * cstep + cy) * L.tap_off_sy + (b * cstep + cx) * L.tap_off_sx +
+                                         (int64_t)k * L.stride_k + (int64_t)n * L.stride_n]
+                                   : 0.f;
+            float tt[4][2];   // A g
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                tt[0][b] = gg[0][b];
+                tt[1][b] = gg[0][b] + gg[1][b];
+                tt[2][b] = gg[0][b] - gg[1][b];
+                tt[3][b] = -gg[1][b];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {   // (A g) A^T
+                u[a * 4 + 0][i] = tt[a][0];
+                u[a * 4 + 1][i] = tt[a][0] + tt[a][1];
+                u[a * 4 + 2][i] = tt[a][0] - tt[a][1];
+                u[a * 4 + 3][i] = -tt[a][1];
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            unsigned pl[3][4];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                const float x0 = u[f][2 * i2], x1 = u[f][2 * i2 + 1];
+                const unsigned hi = w4b_cvt_pk(x0, x1);
+                const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+                const unsigned mid = w4b_cvt_pk(r0, r1);
+                const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
+                pl[0][i2] = hi;
+                pl[1][i2] = mid;
+                pl[2][i2] = w4b_cvt_pk(s0, s1);
+            }
+            const int64_t grp = ((((int64_t)cls * ncog + cog) * nchunks + chunk) * 16 + f) * NT + j;
+#pragma unroll
+            for (int p2 = 0; p2 < 3; ++p2) wp[(grp * 3 + p2) * 64 + hh * 32 + l31] = u32x4{pl[p2][0], pl[p2][1], pl[p2][2], pl[p2][3]};
+        }
+    }
+}
+
+extern "C" int adh_pack_weights_wino32_bf16x3(void* stream, const float* src, const adh_wlayout* L, void* wp) {
+    if (!src || !L || !wp || L->K < 1 || L->Nc < 1) return ADH_E_ARG;
+    if (!((L->KHt == 2 && L->KWt == 2) || (L->KHt == 4 && L->KWt == 4))) return ADH_E_ARG;
+    const int ncls = L->KHt == 4 ? 4 : 1;
+    const int KO = adh_round_up(L->K, 16) / 8;
+    const int NcP = adh_round_up(L->Nc, 32);
+    const int nt = NcP / 32, NT = nt % 3 == 0 ? 3 : (nt % 2 == 0 ? 2 : 1);
+    const int64_t total = (int64_t)ncls * KO * NcP;
+    hipLaunchKernelGGL(pack_weights_wino32_bf16x3_kernel, dim3(adh_min_i(adh_ceil_div(total, 128), 4096)), dim3(128), 0,
+                       (hipStream_t)stream, src, *L, KO, NcP, ncls, NT, reinterpret_cast<u32x4*>(wp));
     return adh_check_launch();
 }
 

@@ -477,7 +477,10 @@ class Engine:
                 if H.value("adh_conv_wino32_supported", C.byref(d)):
                     wino = 32
                     ncls = 4 if gm["KH"] == 4 else 1
-                    wp = self._packed("adh_pack_weights_wino32", w, Lw, ncls * 16 * (Kp // 4) * NcP * 4)
+                    if CONTRACT == "bf16x3":
+                        wp = self._packed("adh_pack_weights_wino32_bf16x3", w, Lw, ncls * 16 * Kp * NcP * 3 // 2)
+                    else:
+                        wp = self._packed("adh_pack_weights_wino32", w, Lw, ncls * 16 * (Kp // 4) * NcP * 4)
                 else:
                     d.dy0 = d.dx0 = gm["dy0"]
                     d.dstep_y = d.dstep_x = gm["dstep"]
@@ -511,6 +514,7 @@ class Engine:
                 d0.residual, d0.res_cstride = y_p.data_ptr(), y_p.stride(2)
                 d0.scale, d0.shift = ss_p[0].data_ptr(), ss_p[1].data_ptr()
                 want_stats = True
+        _B3 = "_bf16x3" if CONTRACT == "bf16x3" else ""      # entry-point suffix of the opt-in contraction
         stats = None
         if want_stats:
             NcP = descs[0][0].NcP
@@ -530,7 +534,7 @@ class Engine:
             arr = (H.ConvDesc * len(descs))(*[dd for dd, _, _, _ in descs])
             work = sum(2.0 * dd.N * dd.VH * dd.VW * dd.KH * dd.KW * kn for (dd, _, _, _), kn in zip(descs, flops_kn))
             try:
-                H.call("adh_conv_wino32_forward_multi", arr, len(descs), work=work, work_exec=work * 4.0 / 9.0,
+                H.call("adh_conv_wino32_forward_multi" + _B3, arr, len(descs), work=work, work_exec=work * 4.0 / 9.0,
                        family="adh_conv_wino32_forward")
                 return stats, total_blocks
             except RuntimeError as e:
@@ -551,7 +555,8 @@ class Engine:
                 st.wait_event(fork)
                 with torch.cuda.stream(st):
                     work = 2.0 * d.N * d.VH * d.VW * d.KH * d.KW * flops_kn[row_i]
-                    H.call("adh_conv_wino32_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
+                    H.call("adh_conv_wino32_forward" + _B3, C.byref(d), work=work, work_exec=work * 4.0 / 9.0,
+                           family="adh_conv_wino32_forward")
                 row += nb
                 row_i += 1
                 continue
@@ -570,7 +575,8 @@ class Engine:
                 H.call("adh_conv_wino43_forward" + ("_bf16x3" if CONTRACT == "bf16x3" else ""), C.byref(d), work=work,
                        work_exec=work * 0.25, family="adh_conv_wino43_forward")
             elif wino == 32:
-                H.call("adh_conv_wino32_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
+                H.call("adh_conv_wino32_forward" + _B3, C.byref(d), work=work, work_exec=work * 4.0 / 9.0,
+                       family="adh_conv_wino32_forward")
             elif wino:
                 H.call("adh_conv_wino_forward", C.byref(d), work=work, work_exec=work * 4.0 / 9.0)
             else:
@@ -1102,13 +1108,17 @@ class Engine:
         N, Hh, Ww, Cc = x.N, x.Hh, x.Ww, x.C
         HW = Hh * Ww
         nblk = H.value("adh_cbam_pool_num_blocks", HW)
-        partial = self._f(N, nblk, 2, Cc)
-        partial_idx = torch.empty((N, nblk, Cc), device=self.device, dtype=torch.int32)
-        pooled = self._f(N, 2, Cc)
-        amax_idx = torch.empty((N, Cc), device=self.device, dtype=torch.int32)
-        H.call("adh_cbam_pool", x.t.data_ptr(), x.cs, N, HW, Cc, partial.data_ptr(), partial_idx.data_ptr(), nblk,
-               pooled.data_ptr(), amax_idx.data_ptr())
-        o = Act(pooled[:, 0, :].contiguous().view(N, 1, 1, Cc), Cc)   # [N,1,1,C] means
+        means = self._f(N, Cc)
+        for c0 in range(0, Cc, 1024):      # the pooling kernel takes <= 1024 channels per launch (resnet50: 2048): channel slices of x
+            cw = min(1024, Cc - c0)
+            partial = self._f(N, nblk, 2, cw)
+            partial_idx = torch.empty((N, nblk, cw), device=self.device, dtype=torch.int32)
+            pooled = self._f(N, 2, cw)
+            amax_idx = torch.empty((N, cw), device=self.device, dtype=torch.int32)
+            H.call("adh_cbam_pool", x.t.data_ptr() + 4 * c0, x.cs, N, HW, cw, partial.data_ptr(), partial_idx.data_ptr(), nblk,
+                   pooled.data_ptr(), amax_idx.data_ptr())
+            means[:, c0:c0 + cw] = pooled[:, 0, :]
+        o = Act(means.view(N, 1, 1, Cc), Cc)   # [N,1,1,C] means
         if self.record:
             def bwd():
                 g = o.grad

@@ -114,6 +114,13 @@ int adh_conv_wino32_forward(void* stream, const adh_conv_desc* d);
  * round of workgroups instead of n. */
 int adh_conv_wino32_forward_multi(void* stream, const adh_conv_desc* descs, int n);
 int adh_pack_weights_wino32(void* stream, const float* src, const adh_wlayout* L, float* wp);
+/* Opt-in bf16 x 3 contraction of the same launches (round 4; host switch ADH_CONTRACT=bf16x3; see adh_conv_wino43_forward_bf16x3):
+ * same descriptors, same epilogue, same statistics rows; d->wp from adh_pack_weights_wino32_bf16x3 (ncls * 16 * Kp * NcP * 6
+ * bytes, Kp = K rounded up to 16, NcP = Nc rounded up to 32).  Replaces the same ATen calls as adh_conv_wino32_forward
+ * (/root/reference models/dehazing/medium_intensity.py:53,63 ConvTranspose2d k4 s2; base_model.py:11-13 Conv2d k4 s2). */
+int adh_conv_wino32_forward_bf16x3(void* stream, const adh_conv_desc* d);
+int adh_conv_wino32_forward_multi_bf16x3(void* stream, const adh_conv_desc* descs, int n);
+int adh_pack_weights_wino32_bf16x3(void* stream, const float* src, const adh_wlayout* L, void* wp);
 
 /* Winograd F(4x4,3x3) on fp32 MFMA (conv_wino43.hip): the same 3x3 stride-1 pad-1 forms as adh_conv_wino_forward at
  * 1/4 of the direct algorithm's MFMA work (F(2x2,3x3): 4/9); needs Cin % 16 == 0.  Replaces the same ATen conv2d calls

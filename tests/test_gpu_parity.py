@@ -685,11 +685,14 @@ def test_stem_weight_gradient(N, Co, Hh, Ww, monkeypatch):
 
 @pytest.mark.parametrize("kind,N,Ci,Co,Hh,Ww", [("conv", 1, 32, 96, 48, 96), ("conv", 2, 16, 64, 26, 50), ("conv", 1, 96, 192, 24, 192),
                                                 ("convT", 1, 64, 96, 12, 48), ("convT", 2, 32, 32, 13, 25), ("convT", 1, 16, 192, 24, 96)])
-def test_winograd32_matches_direct_path(kind, N, Ci, Co, Hh, Ww, monkeypatch):
+@pytest.mark.parametrize("contract", ["fp32", "bf16x3"])
+def test_winograd32_matches_direct_path(kind, N, Ci, Co, Hh, Ww, contract, monkeypatch):
     """k4 s2 convolution / transposed convolution and their data gradients through conv_wino32_kernel (F(3x3,2x2), one or
     four input-parity classes) and through the direct kernels: outputs, BatchNorm partial statistics and the fused
-    residual + ReLU epilogue agree to fp32 rounding; full and ragged 12x48 regions."""
+    residual + ReLU epilogue agree to fp32 rounding; full and ragged 12x48 regions.  The opt-in bf16 x 3 contraction is held to
+    the same tolerance (6e-6 of the output scale)."""
     import adam_dehaze_amd.engine as E
+    monkeypatch.setattr(E, "CONTRACT", contract)
     g = torch.Generator().manual_seed(Ci * 13 + Hh)
     x = torch.randn(N, Hh, Ww, Ci, generator=g).to(DEV)
     if kind == "conv":
