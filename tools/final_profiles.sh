@@ -18,15 +18,23 @@ stats)
 pmc)
   bash tools/pmc_bench.sh
   cp gpurun_out/pmc_bench.json gpurun_out/r04_pmc_bench.json
+  ;;
+pmc2)
+  # SQ counters of the F(4x4,3x3) / F(3x3,2x2) forward kernels, fp32 MFMA and bf16 x 3 contraction, at the headline shapes
   cd /tmp && export TMPDIR=/tmp
-  export ADH_CONTRACT=bf16x3
-  i=0
-  for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
-    i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_b3_$i -- python3 $R/tools/bench_kernels.py --only conv --pass fwd --iters 3 > $R/gpurun_out/pmc_b3_$i.log 2>&1 || echo "pass $i failed"
+  for c in fp32 bf16x3; do
+    export ADH_CONTRACT=$c
+    for sel in conv96 conv384 down96to192 up384to96; do
+      i=0
+      for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
+        i=$((i+1))
+        rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${c}_${sel}_$i -- python3 $R/tools/bench_kernels.py --only $sel --pass fwd --iters 3 > $R/gpurun_out/pmc_${c}_${sel}_$i.log 2>&1 || echo "pass $c $sel $i failed"
+      done
+      echo "=== $c $sel (tools/bench_kernels.py --only $sel --pass fwd --iters 3: 4 launches per pass)" >> $R/gpurun_out/r04_pmc_contract_raw.txt
+      python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_${c}_${sel}_1 $R/gpurun_out/pmc_${c}_${sel}_2 $R/gpurun_out/pmc_${c}_${sel}_3 $R/gpurun_out/pmc_${c}_${sel}_4 | grep -v "pack_weights" >> $R/gpurun_out/r04_pmc_contract_raw.txt 2>&1 || true
+    done
   done
   cd $R
-  python3 tools/pmc_summary.py gpurun_out/pmc_b3_1 gpurun_out/pmc_b3_2 gpurun_out/pmc_b3_3 gpurun_out/pmc_b3_4 > gpurun_out/r04_pmc_bf16x3_raw.txt 2>&1 || true
   ;;
 esac
 echo done
