@@ -328,12 +328,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             int C, const float* __restrict__ mask_ss,
                                                             const uint8_t* __restrict__ mask_bits) {
     __shared__ f32x4 red[2][256];
-    const int CQ = C / 4;
+    // channels in groups of at most 1024 (256 quads, one per thread): one group for every layer of the dehazing branches; the
+    // resnet50 HDEN's 2048-channel BatchNorms (round 4) take two
+  for (int cbase = 0; cbase < C; cbase += 1024) {
+    const int CQ = (C - cbase < 1024 ? C - cbase : 1024) / 4;
     const int R = 256 / CQ;  // pixel rows handled concurrently
     const int cq = threadIdx.x % CQ;
     const int prow = threadIdx.x / CQ;
     const bool active = prow < R;
-    const int c = cq * 4;
+    const int c = cbase + cq * 4;
     f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             for (int u = 0; u < BNB_UNROLL; ++u) {
                 const int64_t q = p + u * R < p1 ? p + u * R : p;
                 g[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g_out + q * g_cs + c));
-                if (mask_bits) mb[u] = mask_bits[(q * CQ + cq) >> 1] >> (4 * (cq & 1));
+                if (mask_bits) mb[u] = mask_bits[(q * (C / 4) + (c >> 2)) >> 1] >> (4 * ((c >> 2) & 1));
                 else if (act == ADH_ACT_RELU && !mask_ss) o[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(out + q * out_cs + c));
                 yy[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + q * y_cs + c));
             }
@@ -389,12 +392,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         *reinterpret_cast<f32x4*>(partials + ((size_t)blockIdx.x * 2 + 0) * C + c) = a;
         *reinterpret_cast<f32x4*>(partials + ((size_t)blockIdx.x * 2 + 1) * C + c) = b;
     }
+    __syncthreads();   // (the next channel group reuses `red`)
+  }
 }
 
 extern "C" int adh_bn_bwd_reduce(void* stream, const float* g_out, int g_cs, const float* out, int out_cs, int act,
                                  const float* y, int y_cs, const float* mean, const float* invstd, float* partials,
                                  int64_t P, int C, const float* mask_ss, const uint8_t* mask_bits) {
-    if (!g_out || !y || !mean || !invstd || !partials || P < 1 || C < 4 || (C & 3) || C > 1024) return ADH_E_ARG;
+    if (!g_out || !y || !mean || !invstd || !partials || P < 1 || C < 4 || (C & 3) || C > 4096) return ADH_E_ARG;
     if (act == ADH_ACT_RELU && !out && !mask_ss && !mask_bits) return ADH_E_ARG;
     if (mask_bits && (((C / 4) & 1) || act != ADH_ACT_RELU)) return ADH_E_ARG;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(adh_bn_bwd_num_blocks(P, C)), dim3(256), 0, (hipStream_t)stream, g_out,

@@ -863,8 +863,9 @@ def test_merged_class_launch_is_bit_equal(N, Ci, Co, Hh, Ww, train, monkeypatch)
         eng._run_gather(eng._launch_plan("conv", 4, 2, 1, wc, "dgrad"), Act(gy, Ci), gx, Co, wc)
         torch.cuda.synchronize()
         res[merged] = (o.t.clone(), gx.clone(), None if bn is None else bn.running_var.clone(), list(calls))
-    assert res[False][3].count("adh_conv_wino32_forward") >= 4 and "adh_conv_wino32_forward_multi" not in res[False][3]
-    assert res[True][3].count("adh_conv_wino32_forward_multi") >= 1 and "adh_conv_wino32_forward" not in res[True][3]
+    names = lambda calls: [c[:-len("_bf16x3")] if c.endswith("_bf16x3") else c for c in calls]     # (fp32 or opt-in entry points)
+    assert names(res[False][3]).count("adh_conv_wino32_forward") >= 4 and "adh_conv_wino32_forward_multi" not in names(res[False][3])
+    assert names(res[True][3]).count("adh_conv_wino32_forward_multi") >= 1 and "adh_conv_wino32_forward" not in names(res[True][3])
     assert torch.equal(res[False][0], res[True][0])
     assert torch.equal(res[False][1], res[True][1])
     if train:

@@ -361,7 +361,9 @@ def test_evaluate_detection_writes_coco_tables(tmp_path):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         res = T.evaluate_detection(cfg, steps=1, score_threshold=0.0)      # random-init detector: keep every detection
-    assert set(res) == {"counts", "hazy", "dehazed"}
+    assert set(res) == {"counts", "hazy", "dehazed", "weights"}
+    # which weights produced the numbers is part of the result: no joint / detector checkpoint exists here
+    assert res["weights"] == {"joint_checkpoint": None, "detector_checkpoint": None, "detector_random_init": True}
     saved = json.load(open(tmp_path / "results" / "detection_results.json"))
     assert saved["counts"] == res["counts"] and sum(res["counts"]["hazy"].values()) == sum(1 for r in saved["detections"]
                                                                                           if r["source"] == "hazy")
@@ -378,7 +380,7 @@ def test_evaluate_detection_writes_coco_tables(tmp_path):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         res2 = T.evaluate_detection(cfg, steps=1)
-    assert set(res2) == {"counts"}
+    assert set(res2) == {"counts", "weights"}
 
 
 def test_comprehensive_evaluation_files_and_keys(tmp_path):
