@@ -82,8 +82,6 @@ _SIGNATURES = {
     "adh_conv_wino43_forward": [vp, PD],
     "adh_conv_wino43_dgrad_bnred": [vp, PD, vp],
     "adh_pack_weights_wino43": [vp, vp, PL, vp],
-    "adh_conv_wino43_forward_pipe": [vp, PD],
-    "adh_conv_wino43_dgrad_bnred_pipe": [vp, PD, vp],
     "adh_conv_wino43_forward_bf16x3": [vp, PD],
     "adh_conv_wino43_dgrad_bnred_bf16x3": [vp, PD, vp],
     "adh_pack_weights_wino43_bf16x3": [vp, vp, PL, vp],

@@ -23,7 +23,11 @@
 //   * contraction: per wave 18 groups (9 frequencies x two 8-channel halves) of 4*NT MFMAs; A = one ds_read_b128 of
 //     V[f][tile][quad ^ swizzle(tile)], B = NT global_load_dwordx4 of U[f][k/4][n][4] (adh_pack_weights_wino43), fetched
 //     two groups ahead with hand-counted waits (conv_wino.hip, w2_load_b: same contract).
-// V is single buffered: a chunk is transformed, then contracted (VALU and fp32 MFMA work do not overlap anyway).
+// V is single buffered: a chunk is transformed, then contracted (VALU and fp32 MFMA work do not overlap anyway -- built and
+// measured in round 4: a form with the transform of the next eight channels pinned inside the MFMA stream of the current eight,
+// V and raw double-buffered at eight channels, was parity-green and exactly as fast; every v_pk_fma_f32 of the transform takes
+// ~16 cycles of the fp32 FMA datapath the MFMA runs on wherever it is issued.  profiles/r04_ab_wino43_pipelined_transform.txt,
+// commit 32ab26b).
 // Epilogue: accumulators -> LDS M[36][32 tiles][32 co] one channel tile at a time, A^T M A and the fused epilogue.
 #include "common.h"
 #ifndef W_STORE_AUX
@@ -336,144 +340,7 @@ __device__ __forceinline__ void w4b_bt_store_staging(f32x4 (&d)[6], float* dst, 
     put(4, n.b * s + r);
 }
 
-
-// ------------------------------------------------------------------------------------------------ pipelined fp32 form (round 4)
-// conv_wino43_kernel<NT, BNRED, false, true>: the same regions, the same arithmetic (fp32 transform, v_mfma_f32_32x32x2_f32 contraction,
-// the same epilogue) with the input transform of the NEXT eight input channels running INSIDE the contraction of the current
-// eight.  One wave per SIMD leaves the wave's issue port idle for ~60 of the 64 cycles of every fp32 MFMA: a few LDS / VALU
-// instructions pinned behind an MFMA cost nothing (the bf16 x 3 form splits its operands that way), and the two-phase form's
-// transform (1.47 of 8.9 us per 16-channel chunk, measured) is exactly such work.  What it takes:
-//   * granularity: HALF chunks of 8 channels.  V[2][36 f][32 tiles][8 ch] (2 x 36 KB) and raw[2][20 pieces][32 slots][8 ch]
-//     (2 x 20 KB) take the LDS the two-phase form's V and raw take; while the contraction reads V[b], the transform turns
-//     raw[b ^ 1] into V[b ^ 1] (column pass raw -> T, barrier, row pass T -> V in place) and the halo of the half after that
-//     arrives in raw[b] by LDS-DMA, one piece behind the first MFMA of groups 1..5;
-//   * thread = (tile, channel PAIR, column / row parity): float2 values, ds_read_b64 / ds_write_b64, v_pk_fma_f32 -- twice the
-//     instructions of the float4 transform at the same bytes; instructions are what the shadows have to spare;
-//   * a 1-D transform of six values is cut into four steps (six reads | two outputs | two | two), one per k-step of a
-//     contraction group, each pinned behind the first MFMA of its k-step with sched_barriers: by the time a step runs, the reads
-//     of the step before have long landed;
-//   * four barriers per 16 channels (column pass done | half boundary | column pass done | chunk boundary), each inside the MFMA
-//     stream: a wave that waits there still has its last MFMA in the pipe.
-// No LDS swizzle anywhere: every access is a contiguous 256-byte run per 32 lanes.
-#define W4P_VBUF 9216                 // floats of one V buffer: 36 f x 32 tiles x 8 ch
-#define W4P_RAWBUF 5120               // floats of one raw buffer: 20 pieces x 32 slots x 8 ch
-static_assert(2 * W4P_VBUF == W4_VF && 2 * W4P_RAWBUF == W4_RAWF, "the pipelined form splits the two-phase form's V and raw in two");
-struct W4PX {
-    f32x2 d[6];      // the six values of the 1-D transform in flight
-    int rp;          // float2 index of this thread's patch pixel (row 0, plane 0) in raw buffer 0
-    int tp;          // float2 index of (tile, channel pair) inside one frequency image
-    int csel;        // column / row parity (wave-uniform)
-    int cb_next;     // byte offset of the first channel of the chunk being staged (wave-uniform)
-    int wave;
-    bool interior;
-};
-// does group FI (0..8) of a half carry a staging piece?  pieces 0..4 ride in groups 1..5
-constexpr int w4p_piece(int G) { return ((G % 9) >= 1 && (G % 9) <= 5) ? 1 : 0; }
-template <int PASS, int K, int B>   // the six reads of column (PASS 1: raw[B]) / row (PASS 2: T in V[B]) K
-__device__ __forceinline__ void w4p_read(W4PX& x, const float* lds) {
-    const f32x2* const l2 = reinterpret_cast<const f32x2*>(lds);
-    if constexpr (PASS == 1) {
-        // patch column c = 2 K + csel sits in plane c & 3 at index tcol + (c >> 2): slot offsets {0, 18, 1} / {9, 26, 10}
-        constexpr int s0 = K == 0 ? 0 : (K == 1 ? 18 : 1), s1 = K == 0 ? 9 : (K == 1 ? 26 : 10);
-        const int idx = (W4_VF + B * W4P_RAWBUF) / 2 + x.rp + (x.csel ? s1 : s0) * 4;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) x.d[i] = l2[idx + i * (W4_ROWSLOTS * 4)];
-    } else {
-        const int idx = B * (W4P_VBUF / 2) + (2 * K + x.csel) * (6 * 128) + x.tp;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) x.d[c] = l2[idx + c * 128];
-    }
-}
-template <int PASS, int K, int B, int PH>   // two of the six outputs (w4_bt_store's expressions)
-__device__ __forceinline__ void w4p_calc(W4PX& x, float* lds, const W4Neg& n) {
-    constexpr int stride = PASS == 1 ? 6 * 128 : 128;
-    f32x2* const dst = reinterpret_cast<f32x2*>(lds) + B * (W4P_VBUF / 2) + (2 * K + x.csel) * (PASS == 1 ? 128 : 6 * 128) + x.tp;
-    const f32x2(&d)[6] = x.d;
-    if constexpr (PH == 0) {
-        dst[0] = W4_A2B2 * d[0] + (n.s2 * d[2] + d[4]);
-        dst[5 * stride] = W4_A2B2 * d[1] + (n.s2 * d[3] + d[5]);
-    } else if constexpr (PH == 1) {
-        const f32x2 p = n.b2 * d[2] + d[4], q = n.b2 * d[1] + d[3];
-        dst[1 * stride] = W4_A * q + p;
-        dst[2 * stride] = n.a * q + p;
-    } else {
-        const f32x2 r = n.a2 * d[2] + d[4], s = n.a2 * d[1] + d[3];
-        dst[3 * stride] = W4_B * s + r;
-        dst[4 * stride] = n.b * s + r;
-    }
-}
-template <int PASS, int K, int B, int STEP>
-__device__ __forceinline__ void w4p_tstep(W4PX& x, float* lds, const W4Neg& n) {
-    if constexpr (STEP == 0) w4p_read<PASS, K, B>(x, lds);
-    else w4p_calc<PASS, K, B, STEP - 1>(x, lds, n);
-}
-template <int SB>   // out-of-image slots of raw[SB] are zeroed after landing (edge regions only); every wave its own pieces
-__device__ __forceinline__ void w4p_fix_raw(const W4PX& x, float* lds, const W4Stage& st) {
-    if (x.interior) return;
-    int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(ln));
-    float* raw = lds + W4_VF + SB * W4P_RAWBUF + x.wave * 256 + ln * 4;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 5; ++u)
-        if (!st.tab_lane[1280 + 256 * u]) *reinterpret_cast<f32x4*>(raw + u * 1024) = z;
-}
-// what rides behind the first MFMA of k-step KS of group GI (half GI / 9, frequency GI % 9)
-template <int NT, int GI, int KS>
-__device__ __forceinline__ void w4p_hook(W4PX& x, float* lds, const W4Stage& st, const W4Neg& n, int vo, f32x4 (&av)[2], const float* vlane) {
-    constexpr int HALF = GI / 9, FI = GI % 9;
-    constexpr int TB = HALF ^ 1;    // the buffers the transform works on (raw[TB] -> V[TB]); the contraction reads V[HALF]
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KS == 0 && w4p_piece(GI) && !(W4_DBG & 8))   // halo of the half after the next one -> raw[HALF]
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(st.lds) + st.lds_wave + HALF * (W4P_RAWBUF * 4) + (FI - 1) * 4096),
-                                                 16, vo, x.cb_next + HALF * 32, 0, 0);
-    if constexpr (!(W4_DBG & 1)) {
-        if constexpr (FI < 3) w4p_tstep<1, FI, TB, KS>(x, lds, n);
-        else if constexpr (FI == 3 && KS == 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!(W4_DBG & 32)) __builtin_amdgcn_s_barrier();   // T complete
-        } else if constexpr (FI >= 4 && FI < 7) w4p_tstep<2, FI - 4, TB, KS>(x, lds, n);
-    }
-    if constexpr (FI == 8 && KS == 0) w4p_fix_raw<HALF>(x, lds, st);
-    if constexpr (FI == 8 && KS == 1) {
-        // half boundary: V[TB] complete, raw[HALF] landed and fixed, every wave holds the operands of its last group of V[HALF]
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(W4_DBG & 32)) __builtin_amdgcn_s_barrier();
-        av[(GI + 1) & 1] = *reinterpret_cast<const f32x4*>(vlane + TB * W4P_VBUF);   // first group of the next half
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int NT, int GI, int KS, int J>
-__device__ __forceinline__ void w4p_mfmas(f32x16 (&acc)[9 * NT], const f32x4& a, const f32x4 (&b)[NT], W4PX& x, float* lds, const W4Stage& st,
-                                          const W4Neg& n, int vo, f32x4 (&av)[2], const float* vlane) {
-    if constexpr (KS < 4) {
-        w4_mfma<w4_in_agpr<NT, GI % 9, J>()>(acc[(GI % 9) * NT + J], a[KS], b[J][KS]);
-        if constexpr (J == 0) w4p_hook<NT, GI, KS>(x, lds, st, n, vo, av, vlane);
-        if constexpr (J + 1 < NT) w4p_mfmas<NT, GI, KS, J + 1>(acc, a, b, x, lds, st, n, vo, av, vlane);
-        else w4p_mfmas<NT, GI, KS + 1, 0>(acc, a, b, x, lds, st, n, vo, av, vlane);
-    }
-}
-// the 18 groups of 16 input channels: groups 0..8 contract V[0] (the chunk's first eight channels) while raw[1] becomes V[1],
-// groups 9..17 contract V[1] while the next chunk's raw[0] becomes V[0]
-template <int NT, int GI>
-__device__ __forceinline__ void w4p_chunk(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], f32x4 (&bv)[3][NT], W4PX& x, float* lds, const float* vlane,
-                                          unsigned b_voff, const float* b_chunk, const float* b_next, int64_t b_fstride, int b_kq2,
-                                          const W4Stage& st, const W4Neg& n) {
-    if constexpr (GI < 18) {
-        constexpr int G2 = GI + 2, G1 = GI + 1;
-        if constexpr (G2 < 18) w4_load_b<NT>(bv[G2 % 3], b_voff, b_chunk + (G2 % 9) * b_fstride + (G2 / 9) * b_kq2);
-        else w4_load_b<NT>(bv[G2 % 3], b_voff, b_next + (G2 - 18) * b_fstride);
-        if constexpr (GI % 9 != 8) av[G1 & 1] = *reinterpret_cast<const f32x4*>(vlane + (G1 / 9) * W4P_VBUF + (G1 % 9) * 256);
-        int vo = 0;
-        if constexpr (w4p_piece(GI) && !(W4_DBG & 8)) vo = st.tab_lane[256 * (GI % 9 - 1)];
-        constexpr int newer = (W4_DBG & 8) ? 0 : w4p_piece(GI + 16) + w4p_piece(GI + 17);   // the pieces of the previous two groups
-        w4_wait_b<2 * NT + newer, NT>(bv[GI % 3]);
-        w4p_mfmas<NT, GI, 0, 0>(acc, av[GI & 1], bv[GI % 3], x, lds, st, n, vo, av, vlane);
-        w4p_chunk<NT, GI + 1>(acc, av, bv, x, lds, vlane, b_voff, b_chunk, b_next, b_fstride, b_kq2, st, n);
-    }
-}
-
-template <int NT, bool BNRED = false, bool BF3 = false, bool PIPE = false>
+template <int NT, bool BNRED = false, bool BF3 = false>
 __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc d, const Wino43Geom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // V | raw | slot tables | .. | red ; M aliases V .. red
     constexpr int RAW0 = BF3 ? W4B_RAW_B / 4 : W4_VF;                   // float offset of the raw halo
@@ -481,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     // fp32 form: [640][4] source byte offset of (slot s, channel quad q) (clamped) and [640][4] slot-inside-image flags;
     // bf16 x 3 form: one entry per slot, [640] offsets then [640] flags, and two raw buffers (chunk c reads buffer c & 1)
     int* const tab_off = reinterpret_cast<int*>(lds + (BF3 ? W4B_TAB_B / 4 : W4_TAB));
-    int* const tab_ok = BF3 ? tab_off + 640 : (PIPE ? tab_off + 1280 : reinterpret_cast<int*>(lds + W4_TABOK));
+    int* const tab_ok = BF3 ? tab_off + 640 : reinterpret_cast<int*>(lds + W4_TABOK);
     float* const red = lds + W4_RED;
 
     const int tid = threadIdx.x;
@@ -526,10 +393,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         if constexpr (BF3) {
             tab_off[s] = off;
             tab_ok[s] = ok;
-        } else if constexpr (PIPE) {   // [640 slots][2 quads]: eight channels per half chunk
-            typedef int i32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<i32x2*>(tab_off + 2 * s) = i32x2{off, off + 16};
-            *reinterpret_cast<i32x2*>(tab_ok + 2 * s) = i32x2{ok, ok};
         } else {
             *reinterpret_cast<i32x4*>(tab_off + 4 * s) = i32x4{off, off + 16, off + 32, off + 48};
             *reinterpret_cast<i32x4*>(tab_ok + 4 * s) = i32x4{ok, ok, ok, ok};
@@ -552,17 +415,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     auto stage_first = [&]() {   // chunk 0 (prologue); the later chunks arrive piece by piece inside the contraction
         int vo[10];   // all table reads first: one LDS round trip instead of ten
 #pragma unroll
-        for (int u = 0; u < 10; ++u) vo[u] = st.tab_lane[TABU * (PIPE ? u % 5 : u)] + (BF3 ? quad16_o : 0);
+        for (int u = 0; u < 10; ++u) vo[u] = st.tab_lane[TABU * u] + (BF3 ? quad16_o : 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 10; ++u) {
-            if constexpr (PIPE)   // pieces 0..4 of the first eight channels -> raw[0], of the second eight -> raw[1]
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + (u / 5) * (W4P_RAWBUF * 4) + (u % 5) * 4096),
-                                                         16, vo[u], (u / 5) * 32, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + u * 4096), 16,
-                                                         vo[u], 0, 0, 0);
-        }
+        for (int u = 0; u < 10; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + u * 4096), 16,
+                                                     vo[u], 0, 0, 0);
     };
     // bf16 x 3 form: next to 27 accumulator tiles, the weight ring and the planes in the making, the contraction has fewer than ten
     // registers to spare: nothing a thread needs only OUTSIDE the contraction may stay live across it.  Such per-thread constants are
@@ -707,47 +565,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (PIPE) {
-        // ---- pipelined form: the first eight channels are transformed here, every later half inside the contraction before it
-        W4PX x;
-        {
-            const int tl = ((wave & 1) << 4) | (lane >> 2), pr = lane & 3;
-            x.rp = ((4 * (tl >> 3)) * W4_ROWSLOTS + (tl & 7)) * 4 + pr;
-            x.tp = tl * 4 + pr;
-        }
-        x.csel = wave >> 1;
-        x.cb_next = 0;
-        x.wave = wave;
-        x.interior = interior;
-        w4p_fix_raw<0>(x, lds, st);
-        w4p_fix_raw<1>(x, lds, st);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        w4p_tstep<1, 0, 0, 0>(x, lds, negc); w4p_tstep<1, 0, 0, 1>(x, lds, negc); w4p_tstep<1, 0, 0, 2>(x, lds, negc); w4p_tstep<1, 0, 0, 3>(x, lds, negc);
-        w4p_tstep<1, 1, 0, 0>(x, lds, negc); w4p_tstep<1, 1, 0, 1>(x, lds, negc); w4p_tstep<1, 1, 0, 2>(x, lds, negc); w4p_tstep<1, 1, 0, 3>(x, lds, negc);
-        w4p_tstep<1, 2, 0, 0>(x, lds, negc); w4p_tstep<1, 2, 0, 1>(x, lds, negc); w4p_tstep<1, 2, 0, 2>(x, lds, negc); w4p_tstep<1, 2, 0, 3>(x, lds, negc);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        w4p_tstep<2, 0, 0, 0>(x, lds, negc); w4p_tstep<2, 0, 0, 1>(x, lds, negc); w4p_tstep<2, 0, 0, 2>(x, lds, negc); w4p_tstep<2, 0, 0, 3>(x, lds, negc);
-        w4p_tstep<2, 1, 0, 0>(x, lds, negc); w4p_tstep<2, 1, 0, 1>(x, lds, negc); w4p_tstep<2, 1, 0, 2>(x, lds, negc); w4p_tstep<2, 1, 0, 3>(x, lds, negc);
-        w4p_tstep<2, 2, 0, 0>(x, lds, negc); w4p_tstep<2, 2, 0, 1>(x, lds, negc); w4p_tstep<2, 2, 0, 2>(x, lds, negc); w4p_tstep<2, 2, 0, 3>(x, lds, negc);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // A: V[b][f = 9 wave + fi][tile = l31][quad h] (one contiguous KB per frequency image: no swizzle)
-        const float* const vlane_p = lds + (wave * 9) * 256 + l31 * 8 + h * 4;
-        av[0] = *reinterpret_cast<const f32x4*>(vlane_p);
-        W4_STAMP(1);
-#pragma unroll 1
-        for (int c = 0; c < g.nchunks; ++c) {
-            const int cn = c + 1 < g.nchunks ? c + 1 : c;   // the last chunk re-stages (and re-transforms) itself: uniform counts
-            x.cb_next = cn * (W4_KC * 4);
-            if (c == 1) W4_STAMP(10);
-            const float* b_chunk = b_wave + (int64_t)(c * 4) * b_kq;
-            const float* b_next = b_wave + (int64_t)(cn * 4) * b_kq;
-            if (!(W4_DBG & 2)) w4p_chunk<NT, 0>(acc, av, bv, x, lds, vlane_p, b_voff, b_chunk, b_next, b_fstride, 2 * b_kq, st, negc);
-            if (c == 1) W4_STAMP(13);
-        }
-    } else {
     fix_raw();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -810,7 +627,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (c == 1) W4_STAMP(13);
-    }
     }
     if constexpr (!BF3) {
         w4_wait_b<0, NT>(bv[0]);
@@ -1034,13 +850,13 @@ extern "C" int adh_conv_wino43_num_blocks(const adh_conv_desc* d) {
     return g.nregions;
 }
 
-template <int NT, bool BNRED = false, bool BF3 = false, bool PIPE = false>
+template <int NT, bool BNRED = false, bool BF3 = false>
 static int launch_wino43(hipStream_t s, const adh_conv_desc* d, Wino43Geom g) {
     g.ncog = d->NcP / (32 * NT);
     const int nblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<NT, BNRED, BF3, PIPE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<NT, BNRED, BF3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_wino43_kernel<NT, BNRED, BF3, PIPE>), dim3(nblocks), dim3(256), BF3 ? W4B_LDS_BYTES : W4_LDS_BYTES, s, *d, g);
+    hipLaunchKernelGGL((conv_wino43_kernel<NT, BNRED, BF3>), dim3(nblocks), dim3(256), BF3 ? W4B_LDS_BYTES : W4_LDS_BYTES, s, *d, g);
     return adh_check_launch();
 }
 
@@ -1080,35 +896,6 @@ extern "C" int adh_conv_wino43_dgrad_bnred(void* stream, const adh_conv_desc* d,
     if (nt % 3 == 0) return launch_wino43<3, true>(s, d, g);
     if (nt % 2 == 0) return launch_wino43<2, true>(s, d, g);
     return launch_wino43<1, true>(s, d, g);
-}
-
-// The same two launches in the pipelined fp32 form (the input transform of the next eight channels inside the contraction of the
-// current eight; see W4PX above).  Same arguments, same packed weights, same arithmetic.
-extern "C" int adh_conv_wino43_forward_pipe(void* stream, const adh_conv_desc* d) {
-    Wino43Geom g;
-    if (!wino43_plan(d, &g)) return ADH_E_UNSUPPORTED;
-    const int rc = wino43_check_args(d);
-    if (rc) return rc;
-    const int nt = d->NcP / 32;
-    hipStream_t s = (hipStream_t)stream;
-    if (nt % 3 == 0) return launch_wino43<3, false, false, true>(s, d, g);
-    if (nt % 2 == 0) return launch_wino43<2, false, false, true>(s, d, g);
-    return launch_wino43<1, false, false, true>(s, d, g);
-}
-
-extern "C" int adh_conv_wino43_dgrad_bnred_pipe(void* stream, const adh_conv_desc* d, const float* bn_mean) {
-    Wino43Geom g;
-    if (!wino43_plan(d, &g)) return ADH_E_UNSUPPORTED;
-    const int rc = wino43_check_args(d);
-    if (rc) return rc;
-    if (!d->residual || !d->scale || !d->shift || !d->stats || !bn_mean || d->act != ADH_ACT_NONE) return ADH_E_ARG;
-    if ((uintptr_t)bn_mean & 15) return ADH_E_ARG;
-    g.bn_mean = bn_mean;
-    const int nt = d->NcP / 32;
-    hipStream_t s = (hipStream_t)stream;
-    if (nt % 3 == 0) return launch_wino43<3, true, false, true>(s, d, g);
-    if (nt % 2 == 0) return launch_wino43<2, true, false, true>(s, d, g);
-    return launch_wino43<1, true, false, true>(s, d, g);
 }
 
 // The same two launches with the contraction on v_mfma_f32_32x32x16_bf16 over exact three-plane bf16 splits of both operands

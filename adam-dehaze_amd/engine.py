@@ -34,11 +34,6 @@ USE_WINO43_WGRAD = os.environ.get("ADH_WINO43_WGRAD", "1") != "0"
 CONTRACT = os.environ.get("ADH_CONTRACT", "fp32")
 if CONTRACT not in ("fp32", "bf16x3"):
     raise ValueError(f"ADH_CONTRACT must be 'fp32' or 'bf16x3', got {CONTRACT!r}")
-# Form of the fp32 F(4x4,3x3) forward / data-gradient launches: "2phase" = transform a 16-channel chunk, then contract it;
-# "pipe" = the transform of the next eight channels inside the MFMA stream of the current eight
-WINO43_FORM = os.environ.get("ADH_WINO43_FORM", "2phase")
-if WINO43_FORM not in ("2phase", "pipe"):
-    raise ValueError(f"ADH_WINO43_FORM must be '2phase' or 'pipe', got {WINO43_FORM!r}")
 W43_WGRAD_ROUNDS = int(os.environ.get("ADH_W43_WGRAD_ROUNDS", "4"))   # dev: rounds of workgroups the pixel splits may form
 USE_SMALL_WGRAD = os.environ.get("ADH_SMALL_WGRAD", "1") != "0"
 USE_FEWOUT = os.environ.get("ADH_FEWOUT", "1") != "0"               # conv_fewout.hip for the <= 4-output-channel 3x3 heads
@@ -51,12 +46,6 @@ CLASS_STREAMS = os.environ.get("ADH_CLASS_STREAMS", "0") != "0"
 # ... and as one grid (adh_conv_wino32_forward_multi): what the streams were after, without their events
 MERGE_CLASSES = os.environ.get("ADH_MERGE_CLASSES", "1") != "0"
 _SIDE_STREAMS: Dict[tuple, list] = {}
-
-
-def _w43_suffix() -> str:
-    if CONTRACT == "bf16x3":
-        return "_bf16x3"
-    return "_pipe" if WINO43_FORM == "pipe" else ""
 
 
 def _side_streams(device: torch.device, n: int):
@@ -580,10 +569,10 @@ class Engine:
             elif wino == "stem":
                 H.call("adh_conv_stem_forward", C.byref(d), work=work)
             elif wino == 43 and bnred is not None:
-                H.call("adh_conv_wino43_dgrad_bnred" + _w43_suffix(), C.byref(d), bnred[2].data_ptr(),
+                H.call("adh_conv_wino43_dgrad_bnred" + ("_bf16x3" if CONTRACT == "bf16x3" else ""), C.byref(d), bnred[2].data_ptr(),
                        work=work, work_exec=work * 0.25, family="adh_conv_wino43_forward")
             elif wino == 43:
-                H.call("adh_conv_wino43_forward" + _w43_suffix(), C.byref(d), work=work,
+                H.call("adh_conv_wino43_forward" + ("_bf16x3" if CONTRACT == "bf16x3" else ""), C.byref(d), work=work,
                        work_exec=work * 0.25, family="adh_conv_wino43_forward")
             elif wino == 32:
                 H.call("adh_conv_wino32_forward" + _B3, C.byref(d), work=work, work_exec=work * 4.0 / 9.0,

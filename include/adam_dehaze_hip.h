@@ -140,11 +140,6 @@ int adh_conv_wino43_forward(void* stream, const adh_conv_desc* d);
  * ResidualBlock (/root/reference models/dehazing/base_model.py:4-24,26-41). */
 int adh_conv_wino43_dgrad_bnred(void* stream, const adh_conv_desc* d, const float* bn_mean);
 int adh_pack_weights_wino43(void* stream, const float* src, const adh_wlayout* L, float* wp);
-/* The same two launches in the PIPELINED fp32 form (round 4): identical arguments, packed weights and arithmetic; the input
- * transform of the next eight input channels runs inside the MFMA stream of the current eight.  Host switch
- * ADH_WINO43_FORM=pipe|2phase.  Replaces the same ATen conv2d calls (/root/reference models/dehazing/base_model.py:11-13,26-41). */
-int adh_conv_wino43_forward_pipe(void* stream, const adh_conv_desc* d);
-int adh_conv_wino43_dgrad_bnred_pipe(void* stream, const adh_conv_desc* d, const float* bn_mean);
 /* Opt-in (round 4; host switch ADH_CONTRACT=bf16x3, the default stays the fp32 MFMA): the same two launches with the contraction
  * on v_mfma_f32_32x32x16_bf16.  Both operands are split EXACTLY into three bf16 planes (x = hi + mid + lo, 3 x 8 significant
  * bits; the transformed input inside the kernel, U at pack time) and the six significant cross terms are accumulated in fp32:

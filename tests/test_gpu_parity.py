@@ -306,11 +306,9 @@ def _fullwidth_vs_oracle(tag, algo, n, h, w, monkeypatch, grad_names=None, grad_
     import adam_dehaze_amd.engine as E
     from adam_dehaze_amd.loss import l1_loss
     monkeypatch.setattr(E, "USE_WINOGRAD", algo != "direct")
-    monkeypatch.setattr(E, "USE_WINO43", {"f43": True, "f43-bf16x3": True, "f43-2phase": True, "f43-pipe": True, "f43-fwd": "fwd", "f43-dgrad": "dgrad"}.get(algo, False))
+    monkeypatch.setattr(E, "USE_WINO43", {"f43": True, "f43-bf16x3": True, "f43-fwd": "fwd", "f43-dgrad": "dgrad"}.get(algo, False))
     if algo == "f43-bf16x3":
         monkeypatch.setattr(E, "CONTRACT", "bf16x3")
-    if algo in ("f43-pipe", "f43-2phase"):   # the non-default form of the fp32 kernel ("f43" runs the default)
-        monkeypatch.setattr(E, "WINO43_FORM", algo[4:])
     ctor, fwd = FULLWIDTH[tag]
     torch.manual_seed(42)
     m = ctor()
@@ -387,7 +385,7 @@ def _fullwidth_vs_oracle(tag, algo, n, h, w, monkeypatch, grad_names=None, grad_
             assert max_abs(v, sd32[k]) < 1e-4, k
 
 
-@pytest.mark.parametrize("algo", ["direct", "f23", "f43", "f43-fwd", "f43-dgrad", "f43-bf16x3", "f43-pipe", "f43-2phase"])
+@pytest.mark.parametrize("algo", ["direct", "f23", "f43", "f43-fwd", "f43-dgrad", "f43-bf16x3"])
 def test_complex_fullwidth_vs_oracle_seeded(algo, monkeypatch):
     """Full-width CORUN-Complex (base 96) on a 2x3x64x96 synthetic foggy batch vs the CPU oracle, through the direct kernels,
     the F(2x2,3x3) and the F(4x4,3x3) Winograd kernels (the default) and the opt-in bf16 x 3 contraction at the SAME gates
@@ -395,7 +393,7 @@ def test_complex_fullwidth_vs_oracle_seeded(algo, monkeypatch):
     _fullwidth_vs_oracle("complex96", algo, 2, 64, 96, monkeypatch)
 
 
-@pytest.mark.parametrize("algo", ["direct", "f43", "f43-bf16x3", "f43-pipe", "f43-2phase"])
+@pytest.mark.parametrize("algo", ["direct", "f43", "f43-bf16x3"])
 @pytest.mark.parametrize("tag", ["medium64", "light32"])
 def test_medium_and_light_fullwidth_vs_oracle_seeded(tag, algo, monkeypatch):
     """The same gates for the full-width MediumIntensityDehazeModel(64) and LightweightDehazeModel(32, 3) (VERDICT r3 weak 2;
@@ -408,7 +406,7 @@ def test_medium_and_light_fullwidth_vs_oracle_seeded(tag, algo, monkeypatch):
 @pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 16, 16, 15, 23), (2, 32, 32, 7, 11), (1, 16, 48, 15, 23), (2, 96, 96, 16, 64),
                                            (1, 64, 192, 24, 40), (3, 32, 16, 8, 96), (1, 16, 16, 41, 66),
                                            (1, 32, 64, 24, 96), (1, 96, 96, 40, 160), (1, 48, 32, 40, 128)])   # interior regions
-@pytest.mark.parametrize("algo", ["f23", "f43", "f43-bf16x3", "f43-pipe", "f43-2phase"])
+@pytest.mark.parametrize("algo", ["f23", "f43", "f43-bf16x3"])
 def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, algo, monkeypatch):
     """Same layer through conv_wino_kernel (F(2x2,3x3)) / conv_wino43_kernel (F(4x4,3x3)) and the direct kernel: outputs
     and BatchNorm partial statistics agree to fp32 rounding, including ragged regions, channel tails (Co < 32) and the
@@ -420,11 +418,9 @@ def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, algo, monkeypatch):
     b = torch.randn(Co, generator=g).to(DEV)
     res = torch.randn(N, Hh, Ww, Co, generator=g).to(DEV)
     got = {}
-    monkeypatch.setattr(E, "USE_WINO43", {"f43": True, "f43-bf16x3": True, "f43-2phase": True, "f43-pipe": True, "f43-fwd": "fwd", "f43-dgrad": "dgrad"}.get(algo, False))
+    monkeypatch.setattr(E, "USE_WINO43", {"f43": True, "f43-bf16x3": True, "f43-fwd": "fwd", "f43-dgrad": "dgrad"}.get(algo, False))
     # the bf16 x 3 contraction (opt-in) is held to the fp32 MFMA path's tolerance
     monkeypatch.setattr(E, "CONTRACT", "bf16x3" if algo == "f43-bf16x3" else "fp32")
-    if algo in ("f43-pipe", "f43-2phase"):
-        monkeypatch.setattr(E, "WINO43_FORM", algo[4:])
     tol = 4e-6 if algo == "f23" else 1.2e-5
     for wino in (False, True):
         monkeypatch.setattr(E, "USE_WINOGRAD", wino)
