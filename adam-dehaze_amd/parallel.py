@@ -37,6 +37,8 @@ two-process rehearsal on one MI355X): gloo has no AVG, so SUM is followed by one
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -65,7 +67,10 @@ class GradientSynchronizer:
         self.world = world_size
         self.bucket_bytes = bucket_bytes
         self.detect_unused = detect_unused
-        self._rebuild_pending = rebuild and world_size > 1
+        # `solo`: nothing to synchronise.  ADH_DIST_FORCE=1 with an initialised process group makes a world of ONE rank issue every
+        # collective all the same: the rehearsal of the RCCL branches on a one-GPU box (bench.py --gpus 1 under that switch)
+        self.solo = world_size <= 1 and not (os.environ.get("ADH_DIST_FORCE", "0") == "1" and _is_dist())
+        self._rebuild_pending = rebuild and not self.solo
         self.index: Dict[int, int] = {id(p): i for i, p in enumerate(self.params)}
         self.arena: Optional[torch.Tensor] = None
         self._layout(list(reversed(range(len(self.params)))))   # backward produces the last layers' gradients first
@@ -121,7 +126,7 @@ class GradientSynchronizer:
         """Route the engine's gradient buffers and grad-ready notifications through this synchronizer."""
         from . import engine as E
         E.GRAD_SINK, E.GRAD_READY = self._sink, self._on_ready
-        if self.sync_bn and self.world > 1:
+        if self.sync_bn and not self.solo:
             E.SYNC_BN = self._sync_bn_all_reduce
         self._installed = True
 
@@ -168,7 +173,7 @@ class GradientSynchronizer:
             self._next_bucket += 1
 
     def _launch(self, b: int):
-        if self.world <= 1:
+        if self.solo:
             return
         bk = self.buckets[b]
         flat = self.arena[bk["start"]:bk["end"]]
@@ -204,13 +209,13 @@ class GradientSynchronizer:
         while self._next_bucket < len(self.buckets):
             self._launch(self._next_bucket)
             self._next_bucket += 1
-        if self.world > 1 and self.detect_unused:
+        if not self.solo and self.detect_unused:
             mask = torch.tensor([1 if r else 0 for r in produced], dtype=torch.int32, device=self.arena.device)
             dist.all_reduce(mask, op=dist.ReduceOp.MAX)
             produced = [bool(x) for x in mask.tolist()]
         for w in self._works:
             w.wait()
-        if self.world > 1 and dist.get_backend() != "nccl":
+        if not self.solo and dist.get_backend() != "nccl":
             self.arena.mul_(1.0 / self.world)
         for i, p in enumerate(self.params):
             if produced[i] or not self.detect_unused:
@@ -236,7 +241,7 @@ class GradientSynchronizer:
         Returns {"backend", "ok", "max_rel", "buckets", "params_bit_equal"}; the same dict on every rank.  This is what makes
         the first RCCL run self-verifying (the nccl branches of this file have only ever been rehearsed under gloo)."""
         self.checking = False
-        if self.world <= 1 or not _is_dist():
+        if self.solo or not _is_dist():
             return {"backend": None, "ok": True, "max_rel": 0.0, "buckets": len(self.buckets), "params_bit_equal": True}
         backend = dist.get_backend()
         dev = self.arena.device
@@ -277,7 +282,7 @@ class GradientSynchronizer:
 
     def all_reduce(self):
         """Non-overlapped form: average whatever is in p.grad now (the round-1 API; finish() without the hooks)."""
-        if self.world <= 1:
+        if self.solo:
             return
         if not self._begun:
             self.begin_step()
@@ -286,7 +291,7 @@ class GradientSynchronizer:
     def _rebuild_from_observed(self):
         """Re-cut the buckets in the order gradients became ready in the first step (rank 0's order for everyone)."""
         order = list(self._observed) + [i for i in self.order if not self._ready[i]]
-        if self.world > 1:
+        if not self.solo:
             t = torch.tensor(order, dtype=torch.int64, device=self.arena.device if dist.get_backend() == "nccl" else "cpu")
             dist.broadcast(t, src=0)
             order = [int(x) for x in t.tolist()]
@@ -297,7 +302,7 @@ class GradientSynchronizer:
     # ------------------------------------------------------------------ replica consistency helpers
     def broadcast_parameters(self, *modules: torch.nn.Module, src: int = 0):
         """Make every rank start from rank `src`'s parameters and buffers (checkpoint loading, RNG-dependent init)."""
-        if self.world <= 1:
+        if self.solo:
             return
         with torch.no_grad():
             seen = set()
@@ -313,7 +318,7 @@ class GradientSynchronizer:
 
 def _broadcast_buffers(self, *modules: torch.nn.Module, src: int = 0):
     """Every rank takes rank `src`'s buffers (BatchNorm running statistics, num_batches_tracked)."""
-    if self.world <= 1:
+    if self.solo:
         return
     with torch.no_grad():
         seen = set()

@@ -478,8 +478,12 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # ADH_DIST_FORCE=1: a world of ONE rank initialises the process group and issues every collective of the N > 1 path (bucket
+    # all-reduces from inside backward, the self-check's gathers): the rehearsal of the RCCL branches on a one-GPU box
+    forced = world == 1 and os.environ.get("ADH_DIST_FORCE", "0") == "1"
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
         backend = os.environ.get("ADH_DIST_BACKEND", "nccl")   # nccl = RCCL over xGMI; gloo only for single-GPU rehearsal
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -498,7 +502,7 @@ def main():
     model = A.HighIntensityDehazeModel().to(device).train()
     opt = None if args.no_adam else Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
     sync = None
-    if world > 1:
+    if world > 1 or forced:
         # flat gradient buckets, all-reduced from inside Engine.backward() as they fill (parallel.py)
         sync = GradientSynchronizer(list(model.parameters()), world)
         sync.broadcast_parameters(model)
@@ -537,18 +541,18 @@ def main():
     # timed region: exactly K steps between barrier + synchronize on both sides
     timer = H.KernelTimer(set(CONV_FAMILIES) | set(HBM_FAMILIES))
     H.TIMER = timer
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
     dt = time.perf_counter() - t0
     H.TIMER = None
-    if world > 1:
+    if world > 1 or forced:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -575,8 +579,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cpu_line, sample = cpu_baseline(args.height, args.width, host_threads())
             parity = headline_parity(sample, device)
-        backend = dist.get_backend() if world > 1 else None
-        coll = "" if world == 1 else (" + RCCL grad all-reduce (flat buckets, overlapped with backward)" if backend == "nccl"
+        backend = dist.get_backend() if (world > 1 or forced) else None
+        coll = "" if (world == 1 and not forced) else (" + RCCL grad all-reduce (flat buckets, overlapped with backward)" if backend == "nccl"
                                       else f" + {backend} grad all-reduce (single-GPU rehearsal backend, NOT RCCL)")
         result = {
             "metric": "images/sec CORUN-Complex fwd+bwd 512x1024 bs=8; PSNR vs CPU ref",
@@ -614,11 +618,11 @@ def main():
             result["split_bf16x3"] = split_bf16x3(step, model, args, H, sample, device)
         print(json.dumps(result))
     if selfcheck is not None and not selfcheck["ok"]:
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
             dist.destroy_process_group()
         raise SystemExit(f"ddp_selfcheck FAILED on rank {rank}: {selfcheck}")
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

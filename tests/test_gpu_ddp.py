@@ -99,6 +99,44 @@ def test_two_rank_training_step_matches_shardwise_oracle(tmp_path, backend):
     assert recs[0]["order"][1] == recs[1]["order"][1]
 
 
+@pytest.mark.parametrize("sync_bn", ["0", "1"])
+def test_one_rank_rccl_rehearsal_issues_every_collective(tmp_path, sync_bn):
+    """The RCCL branches of parallel.py on real hardware with the one GPU a test box has: a process group of ONE rank on the
+    `nccl` backend with ADH_DIST_FORCE=1, which makes GradientSynchronizer issue every collective it would issue at N > 1 --
+    the parameter broadcast, ReduceOp.AVG bucket all-reduces launched from inside Engine.backward() onto RCCL's stream, the
+    bucket-order broadcast after step 0, the self-check's all_gather / MAX / MIN, and (sync_bn=1) the per-layer BatchNorm
+    all-reduces on RCCL's stream.  With one rank every reduction is the identity, so the step must equal the oracle's."""
+    recs = _run_ranks(tmp_path, 1, 35000, ADH_WINOGRAD="0", ADH_DDP_BACKEND="nccl", ADH_DIST_FORCE="1", ADH_DDP_SYNC_BN=sync_bn)
+    rec = recs[0]
+    sc = rec["selfcheck"]
+    assert sc["ok"] and sc["backend"] == "nccl" and sc["params_bit_equal"] and sc["max_rel"] < 1e-5, sc
+    hazy, clear, _ = R.synthetic_batch(2, 32, 48, seed=77)
+    sd = {k: v.clone() for k, v in rec["sd0"].items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+
+    def run():
+        out = R.high_forward(hazy, sd, training=True)
+        loss = F.l1_loss(out, clear)
+        loss.backward()
+        return loss
+    loss = oracle_with_masks(run, rec["masks"])
+    assert abs(float(loss) - rec["loss"]) < 1e-5
+    for k, g in rec["grads"].items():
+        ref = sd[k].grad
+        scale = max(float(ref.abs().max()), 1e-8)
+        if k.startswith("decoder") and k.endswith(".0.bias"):
+            continue      # ConvTranspose bias feeding train-mode BN: true gradient 0
+        assert float((g - ref).abs().max()) < 5e-3 * scale + 2e-7, k
+    for k, v in sd.items():
+        if "running" in k:
+            assert float((rec["bn"][k] - v.detach()).abs().max()) < 1e-5, k
+    assert rec["nbuckets"][0] >= 3 and rec["in_arena"]
+    assert rec["order"][1] == rec["order"][2] and rec["order"][0] != rec["order"][1]      # rebuilt in observed order
+    assert rec["early"][1] >= rec["nbuckets"][1] - 1 and rec["early"][2] >= 1             # in flight before backward returned
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("kernels", ["direct", "winograd"])
 def test_two_rank_sync_bn_matches_the_unsharded_reference(tmp_path, kernels, backend):
