@@ -928,147 +928,143 @@ extern "C" int adh_conv_wino43_dgrad_bnred_bf16x3(void* stream, const adh_conv_d
     return launch_wino43<1, true, true>(s, d, g);
 }
 
+// ------------------------------------------------------------------------------------------------ weight packs
 // U[f = a*6+b][k/4][n][4] = (G g G^T)[a][b];  row of G for point p: [1, p, p^2] / prod_{q != p} (p - q), for inf: [0, 0, 1]
-// (computed in double: the entries of G are not dyadic)
-__global__ void pack_weights_wino43_kernel(const float* __restrict__ src, const adh_wlayout L, int KQ, int NcP,
-                                           f32x4* __restrict__ wp) {
-    // thread = (frequency row fa, channel quad, n): six of the 36 frequencies each
-    const int64_t per_row = (int64_t)KQ * NcP, total = 6 * per_row;
+// (computed in double: the entries of G are not dyadic).
+// Both pack kernels: workgroup = 16 k x 32 n of the filter bank, staged through LDS with coalesced loads (one thread per (k, n) reading
+// its nine taps straight from the OIHW / IOHW tensor touched 64 cache lines per load instruction: 105 us per 384 x 384 layer in the
+// bf16 x 3 form, 4.3 ms per training step over the 41 packs; round 4), thread = (n, frequency row fa, ...): six frequencies each.
+#define W4_PACK_K 16
+#define W4_PACK_N 32
+struct W4PackG { double G[6][3]; };
+__device__ __forceinline__ W4PackG w4_pack_g() {
     const double a = W4_A, b = W4_B;
     const double n0 = a * a * b * b, na = 2.0 * a * a * (a * a - b * b), nb = 2.0 * b * b * (b * b - a * a);
-    const double G[6][3] = {{1.0 / n0, 0.0, 0.0},      {1.0 / na, a / na, a * a / na}, {1.0 / na, -a / na, a * a / na},
-                            {1.0 / nb, b / nb, b * b / nb}, {1.0 / nb, -b / nb, b * b / nb}, {0.0, 0.0, 1.0}};
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int fa = (int)(idx / per_row);
-        const int64_t rem = idx - fa * per_row;
-        const int n = (int)(rem % NcP);
-        const int kq = (int)(rem / NcP);
-        double ga[3];                                     // row fa of G without a dynamically indexed private array
+    return W4PackG{{{1.0 / n0, 0.0, 0.0},      {1.0 / na, a / na, a * a / na}, {1.0 / na, -a / na, a * a / na},
+                    {1.0 / nb, b / nb, b * b / nb}, {1.0 / nb, -b / nb, b * b / nb}, {0.0, 0.0, 1.0}}};
+}
+// g[k][n][m] = the nine taps of filter (k0 + k, n0 + n) in MEMORY order (m = 0 is the lowest address); tap (p, q) sits at
+// m = m0 + p * sy + q * sx.  The taps of one (k, n) pair are nine consecutive floats whenever |sy| = 3 and |sx| = 1 (every 3x3 layer
+// here, forward and flipped); the (k, n) pairs are walked along whichever of the two strides is 9, so that a wave reads long runs.
+template <int TK>
+__device__ __forceinline__ int w4_pack_load_tile(const float* __restrict__ src, const adh_wlayout& L, int k0, int n0,
+                                                 float (*g)[W4_PACK_N][9]) {
+    const int sy = L.tap_off_sy, sx = L.tap_off_sx;
+    const int tapmin = L.tap_off0 + (sy < 0 ? 2 * sy : 0) + (sx < 0 ? 2 * sx : 0);
+    const bool k_inner = L.stride_k == 9;
+    for (int e = threadIdx.x; e < TK * W4_PACK_N * 9; e += blockDim.x) {
+        const int t = e % 9, pr = e / 9;
+        const int k = k_inner ? pr % TK : pr / W4_PACK_N, n = k_inner ? pr / TK : pr % W4_PACK_N;
+        float v = 0.f;
+        if (k0 + k < L.K && n0 + n < L.Nc) v = src[(int64_t)tapmin + t + (int64_t)(k0 + k) * L.stride_k + (int64_t)(n0 + n) * L.stride_n];
+        g[k][n][t] = v;
+    }
+    __syncthreads();
+    return L.tap_off0 - tapmin;
+}
+__device__ __forceinline__ void w4_pack_row(double (&ga)[3], const W4PackG& G, int fa) {   // row fa of G without a dynamically indexed private array
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            ga[p] = G[0][p];
+    for (int p = 0; p < 3; ++p) {
+        ga[p] = G.G[0][p];
 #pragma unroll
-            for (int r = 1; r < 6; ++r) ga[p] = fa == r ? G[r][p] : ga[p];
-        }
-        double g[4][3][3];
+        for (int r = 1; r < 6; ++r) ga[p] = fa == r ? G.G[r][p] : ga[p];
+    }
+}
+
+// grid = (KQ / 2, NcP / 32), 384 threads = 32 n x 6 frequency rows x 2 channel quads (KQ is even: K rounded up to 8)
+__global__ __launch_bounds__(384) void pack_weights_wino43_kernel(const float* __restrict__ src, const adh_wlayout L, int KQ, int NcP,
+                                                                  f32x4* __restrict__ wp) {
+    __shared__ float g[8][W4_PACK_N][9];
+    const int k0 = blockIdx.x * 8, n0 = blockIdx.y * W4_PACK_N;
+    const int m0 = w4_pack_load_tile<8>(src, L, k0, n0, g);
+    const int nl = threadIdx.x & 31, rest = threadIdx.x >> 5, fa = rest % 6, kql = rest / 6;
+    const W4PackG G = w4_pack_g();
+    double ga[3];
+    w4_pack_row(ga, G, fa);
+    const int n = n0 + nl, kq = blockIdx.x * 2 + kql;
+#pragma unroll
+    for (int fb = 0; fb < 6; ++fb) {
+        f32x4 u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = kq * 4 + j;
+            double acc = 0.0;
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int q2 = 0; q2 < 3; ++q2)
-                    g[j][p][q2] = (n < L.Nc && k < L.K)
-                                      ? (double)src[(int64_t)L.tap_off0 + p * L.tap_off_sy + q2 * L.tap_off_sx +
-                                                    (int64_t)k * L.stride_k + (int64_t)n * L.stride_n]
-                                      : 0.0;
+                    acc += ga[p] * G.G[fb][q2] * (double)g[kql * 4 + j][nl][m0 + p * L.tap_off_sy + q2 * L.tap_off_sx];
+            u[j] = (float)acc;
         }
-#pragma unroll
-        for (int fb = 0; fb < 6; ++fb) {
-            f32x4 u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double acc = 0.0;
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-#pragma unroll
-                    for (int q2 = 0; q2 < 3; ++q2) acc += ga[p] * G[fb][q2] * g[j][p][q2];
-                u[j] = (float)acc;
-            }
-            wp[((int64_t)(fa * 6 + fb) * KQ + kq) * NcP + n] = u;
-        }
+        wp[((int64_t)(fa * 6 + fb) * KQ + kq) * NcP + n] = u;
     }
+}
+
+static bool w4_pack_layout_ok(const adh_wlayout* L) {
+    return (L->tap_off_sy == 3 || L->tap_off_sy == -3) && (L->tap_off_sx == 1 || L->tap_off_sx == -1);
 }
 
 extern "C" int adh_pack_weights_wino43(void* stream, const float* src, const adh_wlayout* L, float* wp) {
     if (!src || !L || !wp || L->K < 1 || L->Nc < 1 || L->KHt != 3 || L->KWt != 3) return ADH_E_ARG;
+    if (!w4_pack_layout_ok(L)) return ADH_E_UNSUPPORTED;   // taps of one filter must be nine consecutive floats (any 3x3 OIHW / IOHW tensor, flipped or not)
     const int KQ = adh_round_up(L->K, 8) / 4;
     const int NcP = adh_round_up(L->Nc, 32);
-    const int64_t total = (int64_t)6 * KQ * NcP;
-    hipLaunchKernelGGL(pack_weights_wino43_kernel, dim3(adh_min_i(adh_ceil_div(total, 128), 8192)), dim3(128), 0,
-                       (hipStream_t)stream, src, *L, KQ, NcP, reinterpret_cast<f32x4*>(wp));
+    hipLaunchKernelGGL(pack_weights_wino43_kernel, dim3(KQ / 2, NcP / 32), dim3(384), 0, (hipStream_t)stream, src, *L, KQ, NcP,
+                       reinterpret_cast<f32x4*>(wp));
     return adh_check_launch();
 }
 
 // The same U = G g G^T (computed in double, rounded to fp32 exactly as above), split into three bf16 planes and laid out for
 // conv_wino43_kernel<NT, *, true>: [channel group of 32 NT][chunk of 16 k][36 f][NT tiles][3 planes][half h][32 n][8 k] bf16 (the
 // eight k of half h: channels 4h .. 4h+3 and 8+4h .. 8+4h+3 of the chunk), NT as the launch picks it from NcP.  wp: 36 * Kp * NcP * 6 bytes (Kp = K rounded up to 16, NcP = Nc rounded up to 32).
-__global__ void pack_weights_wino43_bf16x3_kernel(const float* __restrict__ src, const adh_wlayout L, int KO, int NcP, int NT,
-                                                  u32x4* __restrict__ wp) {
-    // thread = (frequency row fa, eight k, n): six of the 36 frequencies each (one thread per (eight k, n) with all 36 took
-    // 105 us per 384 x 384 layer -- 4 ms per training step over the 41 packs; round 4)
-    const int64_t per_row = (int64_t)KO * NcP, total = 6 * per_row;
-    const int nchunks = KO / 2;
-    const double a = W4_A, b = W4_B;
-    const double n0 = a * a * b * b, na = 2.0 * a * a * (a * a - b * b), nb = 2.0 * b * b * (b * b - a * a);
-    const double G[6][3] = {{1.0 / n0, 0.0, 0.0},      {1.0 / na, a / na, a * a / na}, {1.0 / na, -a / na, a * a / na},
-                            {1.0 / nb, b / nb, b * b / nb}, {1.0 / nb, -b / nb, b * b / nb}, {0.0, 0.0, 1.0}};
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int fa = (int)(idx / per_row);
-        const int64_t rem = idx - fa * per_row;
-        const int n = (int)(rem % NcP);
-        const int ko = (int)(rem / NcP);                 // the eight k of lane half hh of chunk `chunk`
-        const int cog = n / (32 * NT), j = (n >> 5) % NT, l31 = n & 31, chunk = ko >> 1, hh = ko & 1;
-        double ga[3];                                     // row fa of G without a dynamically indexed private array
+// grid = (chunks, NcP / 32), 384 threads = 32 n x 6 frequency rows x 2 lane halves
+__global__ __launch_bounds__(384) void pack_weights_wino43_bf16x3_kernel(const float* __restrict__ src, const adh_wlayout L, int nchunks, int NcP,
+                                                                         int NT, u32x4* __restrict__ wp) {
+    __shared__ float g[W4_PACK_K][W4_PACK_N][9];
+    const int chunk = blockIdx.x, n0 = blockIdx.y * W4_PACK_N;
+    const int m0 = w4_pack_load_tile<W4_PACK_K>(src, L, chunk * 16, n0, g);
+    const int l31 = threadIdx.x & 31, rest = threadIdx.x >> 5, fa = rest % 6, hh = rest / 6;
+    const W4PackG G = w4_pack_g();
+    double ga[3];
+    w4_pack_row(ga, G, fa);
+    const int nt = n0 >> 5, cog = nt / NT, j = nt % NT;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            ga[p] = G[0][p];
+    for (int fb = 0; fb < 6; ++fb) {
+        unsigned pl[3][4];
 #pragma unroll
-            for (int r = 1; r < 6; ++r) ga[p] = fa == r ? G[r][p] : ga[p];
-        }
-        float g[8][3][3];
+        for (int i2 = 0; i2 < 4; ++i2) {
+            float u2[2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            // k-slot i of lane half hh = the kernel's A operand: channel quads hh and 2 + hh of the chunk
-            const int k = chunk * 16 + (i < 4 ? 4 * hh + i : 8 + 4 * hh + (i - 4));
+            for (int e = 0; e < 2; ++e) {
+                // k-slot i of lane half hh = the kernel's A operand: channel quads hh and 2 + hh of the chunk
+                const int i = 2 * i2 + e, kl = i < 4 ? 4 * hh + i : 8 + 4 * hh + (i - 4);
+                double acc = 0.0;
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int q2 = 0; q2 < 3; ++q2)
-                    g[i][p][q2] = (n < L.Nc && k < L.K)
-                                      ? src[(int64_t)L.tap_off0 + p * L.tap_off_sy + q2 * L.tap_off_sx + (int64_t)k * L.stride_k +
-                                            (int64_t)n * L.stride_n]
-                                      : 0.f;
-        }
-#pragma unroll
-        for (int fb = 0; fb < 6; ++fb) {
-            unsigned pl[3][4];
-#pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {
-                float u2[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-#pragma unroll
-                        for (int q2 = 0; q2 < 3; ++q2) acc += ga[p] * G[fb][q2] * (double)g[2 * i2 + e][p][q2];
-                    u2[e] = (float)acc;
-                }
-                const unsigned hi = w4b_cvt_pk(u2[0], u2[1]);
-                const float r0 = u2[0] - __builtin_bit_cast(float, hi << 16), r1 = u2[1] - __builtin_bit_cast(float, hi & 0xffff0000u);
-                const unsigned mid = w4b_cvt_pk(r0, r1);
-                const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
-                pl[0][i2] = hi;
-                pl[1][i2] = mid;
-                pl[2][i2] = w4b_cvt_pk(s0, s1);
+                    for (int q2 = 0; q2 < 3; ++q2) acc += ga[p] * G.G[fb][q2] * (double)g[kl][l31][m0 + p * L.tap_off_sy + q2 * L.tap_off_sx];
+                u2[e] = (float)acc;
             }
-            const int64_t grp = (((int64_t)cog * nchunks + chunk) * 36 + fa * 6 + fb) * NT + j;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wp[(grp * 3 + p) * 64 + hh * 32 + l31] = u32x4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+            const unsigned hi = w4b_cvt_pk(u2[0], u2[1]);
+            const float r0 = u2[0] - __builtin_bit_cast(float, hi << 16), r1 = u2[1] - __builtin_bit_cast(float, hi & 0xffff0000u);
+            const unsigned mid = w4b_cvt_pk(r0, r1);
+            const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
+            pl[0][i2] = hi;
+            pl[1][i2] = mid;
+            pl[2][i2] = w4b_cvt_pk(s0, s1);
         }
+        const int64_t grp = (((int64_t)cog * nchunks + chunk) * 36 + fa * 6 + fb) * NT + j;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wp[(grp * 3 + p) * 64 + hh * 32 + l31] = u32x4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
     }
 }
 
 extern "C" int adh_pack_weights_wino43_bf16x3(void* stream, const float* src, const adh_wlayout* L, void* wp) {
     if (!src || !L || !wp || L->K < 1 || L->Nc < 1 || L->KHt != 3 || L->KWt != 3) return ADH_E_ARG;
-    const int KO = adh_round_up(L->K, 16) / 8;
+    if (!w4_pack_layout_ok(L)) return ADH_E_UNSUPPORTED;
+    const int nchunks = adh_round_up(L->K, 16) / 16;
     const int NcP = adh_round_up(L->Nc, 32);
     const int nt = NcP / 32, NT = nt % 3 == 0 ? 3 : (nt % 2 == 0 ? 2 : 1);
-    const int64_t total = (int64_t)6 * KO * NcP;
-    hipLaunchKernelGGL(pack_weights_wino43_bf16x3_kernel, dim3(adh_min_i(adh_ceil_div(total, 128), 8192)), dim3(128), 0,
-                       (hipStream_t)stream, src, *L, KO, NcP, NT, reinterpret_cast<u32x4*>(wp));
+    hipLaunchKernelGGL(pack_weights_wino43_bf16x3_kernel, dim3(nchunks, NcP / 32), dim3(384), 0, (hipStream_t)stream, src, *L, nchunks, NcP, NT,
+                       reinterpret_cast<u32x4*>(wp));
     return adh_check_launch();
 }
