@@ -17,10 +17,16 @@ __device__ __forceinline__ unsigned w4b_cvt_pk(float a, float b) {
     const f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-template <bool AGPR>
+// (Z: C = 0 instead of the accumulator's old contents -- the first MFMA on a tile in a region, conv_wino43.hip)
+template <bool AGPR, bool Z = false>
 __device__ __forceinline__ void w4b_mfma(f32x16& c, const u32x4& a, const u32x4& b) {
-    if constexpr (AGPR) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    if constexpr (Z) {
+        if constexpr (AGPR) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "+a"(c) : "v"(a), "v"(b));
+        else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "+v"(c) : "v"(a), "v"(b));
+    } else {
+        if constexpr (AGPR) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+        else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
 }
 // the three planes of one (frequency, 32-channel tile) of U: [plane][64 lanes][16 B] = 3 KB contiguous (adh_pack_weights_wino43_bf16x3)
 __device__ __forceinline__ void w4b_load_b(u32x4 (&b)[3], unsigned voff, const char* sbase) {

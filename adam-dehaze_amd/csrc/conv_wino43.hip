@@ -43,17 +43,18 @@
 #define W4_STORE_NOPS 1   // wait states - 1 after each epilogue store (see the comment at the store)
 #endif
 #define W4_KC 16
+#define W4_ZERO_C false   // (see the zeroing of the accumulators at the top of a region)
 #define W4_TILES 32
 #define W4_VF (36 * W4_TILES * W4_KC)              // floats of V (73,728 B)
 #define W4_SLOTS 612                               // pixel slots of the raw halo: 18 rows x 34 columns
 #define W4_ROWSLOTS 34
 #define W4_RAWF (40 * 256)                         // floats of the raw buffer: 40 DMA pieces of 16 slots (640 >= 612 slots)
-#define W4_TAB (W4_VF + W4_RAWF)                   // float offset of the lane offset table [640 slots][4 quads]
-#define W4_TABOK (W4_TAB + 4 * 640)                // [640 slots][4 quads] slot-inside-image flags (same indexing: one lane pointer)
-#define W4_MF (36 * W4_TILES * 32)                 // floats of the epilogue's M (147,456 B: spans V, raw and the tables)
-#define W4_RED W4_MF                               // statistics scratch (behind M)
+#define W4_TAB (W4_VF + W4_RAWF)                   // float offset of the two lane offset tables [2][640 slots][4 quads] (this region's / the next one's)
+#define W4_TABF (4 * 640)                          // floats of one table
+#define W4_MF (36 * 16 * 32)                       // floats of the epilogue's M: 36 frequencies x 16 tiles x 32 co = exactly V (73,728 B)
+#define W4_RED (W4_TAB + 2 * W4_TABF)              // statistics scratch (behind the tables)
 #define W4_LDS_BYTES ((W4_RED + 2 * 8 * 32) * 4)
-static_assert(W4_TABOK + 4 * 640 <= W4_MF, "tables must end before the statistics scratch");
+static_assert(W4_MF <= W4_VF, "the epilogue's M must not reach the raw halo: the next region's first chunk lands there meanwhile");
 #ifndef W4_P2
 #define W4_P2 0                                    // DMA pieces (of 10 per wave and chunk) issued during transform pass 2 ...
 #endif
@@ -74,9 +75,10 @@ static_assert(W4_TABOK + 4 * 640 <= W4_MF, "tables must end before the statistic
 // one entry per slot (the channel quad is added per lane).
 #define W4B_RAW_B 73728
 #define W4B_RAWBUF_B 40960
-#define W4B_TAB_B 155648
-#define W4B_LDS_BYTES 160768
-static_assert(W4B_LDS_BYTES >= W4_LDS_BYTES && W4B_LDS_BYTES <= 160 * 1024, "LDS map of the bf16 x 3 variant");
+#define W4B_TAB_B 155648                           // two tables of 640 offsets (this region's / the next one's)
+#define W4B_RED_B (W4B_TAB_B + 2 * 2560)
+#define W4B_LDS_BYTES (W4B_RED_B + 2048)
+static_assert(W4B_LDS_BYTES <= 160 * 1024, "LDS map of the bf16 x 3 variant");
 #define B3_NO_SPLIT ((W4_DBG & 16) != 0)
 #include "bf16x3.h"
 
@@ -84,7 +86,7 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr4;
 
 #ifdef W4_PROF   // dev build (tools/prof_wino43.sh): per-workgroup s_memtime stamps and the CU each workgroup ran on
 __device__ unsigned long long w4_prof_buf[16384 * 32];
-#define W4_STAMP(i) do { if (tid == 0 && bid < 16384) w4_prof_buf[bid * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define W4_STAMP(i) do { if (tid == 0 && v < 16384) w4_prof_buf[v * 32 + (i)] = __builtin_readcyclecounter(); } while (0)   // v = the virtual block id (one record per region)
 extern "C" int adh_w4_prof_read(void* dst) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(w4_prof_buf), sizeof(w4_prof_buf)) == hipSuccess ? 0 : -1;
 }
@@ -98,6 +100,7 @@ struct Wino43Geom {
     int nchunks;
     int KQtot;
     int ncog;
+    int nvblocks;                // virtual blocks = 8-aligned regions x output-channel groups, dealt to the persistent workgroups
     const float* bn_mean;        // BNRED launches: the producing layer's batch mean (centres the second sum)
 };
 
@@ -111,18 +114,27 @@ constexpr bool w4_in_agpr() {
     else if constexpr (nv <= 9) return !(J == 0 && FI >= 9 - nv);
     else return !(J == 0 || (J == 1 && FI >= 9 - (nv - 9)));
 }
-template <bool AGPR>
+// Z: the first MFMA on an accumulator tile in a region's first chunk takes C = 0 instead of the tile (432 registers per lane are
+// not zeroed once per region: ~1 us of v_mov / v_accvgpr_write with nothing to hide behind in a persistent workgroup).  The
+// constraint stays "+": the compiler sees a read-modify-write either way, the hardware ignores the old contents.
+template <bool AGPR, bool Z = false>
 __device__ __forceinline__ void w4_mfma(f32x16& c, float a, float b) {
-    if constexpr (AGPR) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    if constexpr (Z) {
+        if constexpr (AGPR) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "+a"(c) : "v"(a), "v"(b));
+        else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "+v"(c) : "v"(a), "v"(b));
+    } else {
+        if constexpr (AGPR) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+        else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
 }
 // one group: local frequency FI, NT output-channel tiles, k-steps KK .. KEND-1 (a whole group: 0 .. 3)
-template <int NT, int FI, int KK, int J, int KEND = 4>
+// (Z: this group is the first one on its accumulator tiles in the region: k-step 0 starts them from zero)
+template <int NT, int FI, int KK, int J, int KEND = 4, bool Z = false>
 __device__ __forceinline__ void w4_group(f32x16 (&acc)[9 * NT], const f32x4& a, const f32x4 (&b)[NT]) {
     if constexpr (KK < KEND) {
-        w4_mfma<w4_in_agpr<NT, FI, J>()>(acc[FI * NT + J], a[KK], b[J][KK]);
-        if constexpr (J + 1 < NT) w4_group<NT, FI, KK, J + 1, KEND>(acc, a, b);
-        else w4_group<NT, FI, KK + 1, 0, KEND>(acc, a, b);
+        w4_mfma<w4_in_agpr<NT, FI, J>(), (Z && KK == 0)>(acc[FI * NT + J], a[KK], b[J][KK]);
+        if constexpr (J + 1 < NT) w4_group<NT, FI, KK, J + 1, KEND, Z>(acc, a, b);
+        else w4_group<NT, FI, KK + 1, 0, KEND, Z>(acc, a, b);
     }
 }
 // does contraction group G carry a staging piece?  (dev build W4_DBG & 8: no staging inside the loop)
@@ -183,28 +195,80 @@ __device__ __forceinline__ void w4_bt_store(f32x4 (&d)[6], float* dst, int strid
     *reinterpret_cast<f32x4*>(dst + 4 * stride) = n.b * s + r;
 }
 
-// accumulators of channel tile J -> M[9 wave + FI][tile row 8 (R >> 2) + 2 (R & 3) + h][l31] (h, l31 are in `addr`), straight
-// from the register class they live in (DS instructions take AGPR data operands on gfx950)
-template <int NT, int J, int FI, int R>
-__device__ __forceinline__ void w4_store_m(const f32x16 (&acc)[9 * NT], unsigned addr) {
+// accumulators of channel tile J, tile half TH (accumulator registers 8 TH .. 8 TH + 7 = MFMA rows 16 TH .. 16 TH + 15) ->
+// M[9 wave + FI][tile row 8 ((R >> 2) & 1) + 2 (R & 3) + h][l31] (h, l31 are in `addr`), straight from the register class they live
+// in (DS instructions take AGPR data operands on gfx950).  M holds 16 tiles: a frequency is 16 rows x 128 B = 2 KB.
+template <int NT, int J, int TH, int FI, int R>
+__device__ __forceinline__ void w4_store_mh_(const f32x16 (&acc)[9 * NT], unsigned addr) {
     if constexpr (FI < 9) {
-        // registers R and R + 1 sit two tile rows = 256 B apart: one ds_write2st64_b32 (offsets in units of 256 B) moves both
-        constexpr int off = FI * 16 + (R >> 2) * 4 + (R & 3);
+        // registers RR and RR + 1 sit two tile rows = 256 B apart: one ds_write2st64_b32 (offsets in units of 256 B) moves both
+        constexpr int RR = 8 * TH + R;
+        constexpr int off = FI * 8 + ((R >> 2) & 1) * 4 + (R & 3);
         if constexpr (w4_in_agpr<NT, FI, J>())
-            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "a"(acc[FI * NT + J][R]),
-                         "a"(acc[FI * NT + J][R + 1]), "n"(off), "n"(off + 1)
+            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "a"(acc[FI * NT + J][RR]),
+                         "a"(acc[FI * NT + J][RR + 1]), "n"(off), "n"(off + 1)
                          : "memory");
         else
-            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(acc[FI * NT + J][R]),
-                         "v"(acc[FI * NT + J][R + 1]), "n"(off), "n"(off + 1)
+            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(acc[FI * NT + J][RR]),
+                         "v"(acc[FI * NT + J][RR + 1]), "n"(off), "n"(off + 1)
                          : "memory");
-        if constexpr (R + 2 < 16) w4_store_m<NT, J, FI, R + 2>(acc, addr);
-        else w4_store_m<NT, J, FI + 1, 0>(acc, addr);
+        if constexpr (R + 2 < 8) w4_store_mh_<NT, J, TH, FI, R + 2>(acc, addr);
+        else w4_store_mh_<NT, J, TH, FI + 1, 0>(acc, addr);
+    }
+}
+template <int NT, int J>
+__device__ __forceinline__ void w4_store_mh(const f32x16 (&acc)[9 * NT], unsigned addr, int th) {   // th: a constant after unrolling
+    if (th == 0) w4_store_mh_<NT, J, 0, 0, 0>(acc, addr);
+    else w4_store_mh_<NT, J, 1, 0, 0>(acc, addr);
+}
+// one frequency (four instructions) of the same: the epilogue deals the next round's M write over the pixel steps of the current
+// round's row pass (36 ds_write2st64_b32 in a row stall the wave on the LDS queue for ~0.45 us; between VALU work and stores they are free)
+template <int NT, int J, int TH, int FI>
+__device__ __forceinline__ void w4_store_mh_one(const f32x16 (&acc)[9 * NT], unsigned addr) {
+#pragma unroll
+    for (int R = 0; R < 8; R += 2) {
+        const int RR = 8 * TH + R;
+        const int off = FI * 8 + ((R >> 2) & 1) * 4 + (R & 3);
+        if constexpr (w4_in_agpr<NT, FI, J>())
+            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "a"(acc[FI * NT + J][RR]),
+                         "a"(acc[FI * NT + J][RR + 1]), "n"(off), "n"(off + 1)
+                         : "memory");
+        else
+            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(acc[FI * NT + J][RR]),
+                         "v"(acc[FI * NT + J][RR + 1]), "n"(off), "n"(off + 1)
+                         : "memory");
+    }
+}
+template <int NT, int J, int TH>
+__device__ __forceinline__ void w4_store_mh_fi(const f32x16 (&acc)[9 * NT], unsigned addr, int fi) {   // fi: a constant after unrolling
+    if (fi == 0) w4_store_mh_one<NT, J, TH, 0>(acc, addr);
+    if (fi == 1) w4_store_mh_one<NT, J, TH, 1>(acc, addr);
+    if (fi == 2) w4_store_mh_one<NT, J, TH, 2>(acc, addr);
+    if (fi == 3) w4_store_mh_one<NT, J, TH, 3>(acc, addr);
+    if (fi == 4) w4_store_mh_one<NT, J, TH, 4>(acc, addr);
+    if (fi == 5) w4_store_mh_one<NT, J, TH, 5>(acc, addr);
+    if (fi == 6) w4_store_mh_one<NT, J, TH, 6>(acc, addr);
+    if (fi == 7) w4_store_mh_one<NT, J, TH, 7>(acc, addr);
+    if (fi == 8) w4_store_mh_one<NT, J, TH, 8>(acc, addr);
+}
+// frequency fi of round (j, th) (constants after unrolling; nothing for j >= NT)
+template <int NT>
+__device__ __forceinline__ void w4_store_mh_round(const f32x16 (&acc)[9 * NT], unsigned addr, int j, int th, int fi) {
+    if (j == 0 && th == 0) w4_store_mh_fi<NT, 0, 0>(acc, addr, fi);
+    if (j == 0 && th == 1) w4_store_mh_fi<NT, 0, 1>(acc, addr, fi);
+    if constexpr (NT > 1) {
+        if (j == 1 && th == 0) w4_store_mh_fi<NT, 1, 0>(acc, addr, fi);
+        if (j == 1 && th == 1) w4_store_mh_fi<NT, 1, 1>(acc, addr, fi);
+    }
+    if constexpr (NT > 2) {
+        if (j == 2 && th == 0) w4_store_mh_fi<NT, 2, 0>(acc, addr, fi);
+        if (j == 2 && th == 1) w4_store_mh_fi<NT, 2, 1>(acc, addr, fi);
     }
 }
 
 // runs the 18 groups of one chunk; GI = group index (frequency GI % 9, channel half GI / 9)
-template <int NT, int GI>
+// (FIRST: the region's first chunk -- groups 0 .. 8 start their accumulator tiles from zero)
+template <int NT, int GI, bool FIRST = false>
 __device__ __forceinline__ void w4_chunk(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], f32x4 (&bv)[3][NT], const float* vlane,
                                          const float* vlane1, unsigned b_voff, const float* b_chunk, const float* b_next, int64_t b_fstride,
                                          int b_kq2, const W4Stage& st) {
@@ -222,7 +286,7 @@ __device__ __forceinline__ void w4_chunk(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], 
             constexpr int u = W4_P2 + GI - W4_PIECE_G0;
             const int vo = st.tab_lane[256 * u];
             w4_wait_b<2 * NT + w4_piece(GI - 2) + w4_piece(GI - 1), NT>(bv[GI % 3]);
-            w4_group<NT, GI % 9, 0, 0, 1>(acc, av[GI & 1], bv[GI % 3]);
+            w4_group<NT, GI % 9, 0, 0, 1, (FIRST && GI < 9)>(acc, av[GI & 1], bv[GI % 3]);
             __builtin_amdgcn_sched_barrier(0);
             // one piece of the next chunk's halo, behind the first k-step: the MFMA pipe is busy for NT * 64 cycles and the
             // raw buffer has no reader between the transform of this chunk and the end of its contraction
@@ -232,10 +296,30 @@ __device__ __forceinline__ void w4_chunk(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], 
             w4_group<NT, GI % 9, 1, 0>(acc, av[GI & 1], bv[GI % 3]);
         } else {
             w4_wait_b<2 * NT + w4_piece(GI - 2) + w4_piece(GI - 1), NT>(bv[GI % 3]);
-            w4_group<NT, GI % 9, 0, 0>(acc, av[GI & 1], bv[GI % 3]);
+            w4_group<NT, GI % 9, 0, 0, 4, (FIRST && GI < 9)>(acc, av[GI & 1], bv[GI % 3]);
         }
-        w4_chunk<NT, GI + 1>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, b_kq2, st);
+        w4_chunk<NT, GI + 1, FIRST>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, b_kq2, st);
     }
+}
+
+// the whole contraction of one chunk (fp32 form): groups 0 and 1 by hand (their weights were requested before the transform), then w4_chunk
+template <int NT, bool FIRST>
+__device__ __forceinline__ void w4_contract(f32x16 (&acc)[9 * NT], f32x4 (&av)[2], f32x4 (&bv)[3][NT], const float* vlane, const float* vlane1,
+                                            unsigned b_voff, const float* b_chunk, const float* b_next, int64_t b_fstride, int b_kq,
+                                            const W4Stage& st) {
+    av[0] = *reinterpret_cast<const f32x4*>(vlane);
+    // group 0
+    w4_load_b<NT>(bv[2], b_voff, b_chunk + 2 * b_fstride);
+    av[1] = *reinterpret_cast<const f32x4*>(vlane + 1 * (W4_TILES * W4_KC));
+    w4_wait_b<2 * NT + w4_p2_pieces(), NT>(bv[0]);
+    w4_group<NT, 0, 0, 0, 4, FIRST>(acc, av[0], bv[0]);
+    // group 1
+    w4_load_b<NT>(bv[0], b_voff, b_chunk + 3 * b_fstride);
+    av[0] = *reinterpret_cast<const f32x4*>(vlane + 2 * (W4_TILES * W4_KC));
+    w4_wait_b<2 * NT + w4_p2_pieces(), NT>(bv[1]);
+    w4_group<NT, 1, 0, 0, 4, FIRST>(acc, av[1], bv[1]);
+    // groups 2..17
+    w4_chunk<NT, 2, FIRST>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, 2 * b_kq, st);
 }
 
 // ------------------------------------------------------------------------------------------------ bf16 x 3 contraction (helpers: bf16x3.h)
@@ -277,7 +361,7 @@ __device__ __forceinline__ void w4b_gap(W4BNext& n, const float* vlane, const fl
 #ifndef W4B_P1
 #define W4B_P1 5      // dev: staging pieces issued in pass 1 (the rest in pass 2)
 #endif
-template <int NT, int G>
+template <int NT, int G, bool FIRST = false>   // FIRST: the region's first chunk -- every group starts its accumulator tile from zero
 __device__ __forceinline__ void w4b_groups(f32x16 (&acc)[9 * NT], u32x4 (&a)[3], W4BNext& n, u32x4 (&bv)[3][3], const float* vlane,
                                            const float* vlane1, unsigned b_voff, const char* b_chunk, float m1) {
     if constexpr (G < 9 * NT) {
@@ -287,7 +371,7 @@ __device__ __forceinline__ void w4b_groups(f32x16 (&acc)[9 * NT], u32x4 (&a)[3],
         constexpr bool agpr = w4_in_agpr<NT, FI, J>();
         u32x4(&b)[3] = bv[G % 3];
         w4b_wait_b<newer>(b);
-        w4b_mfma<agpr>(acc[G], a[0], b[0]);
+        w4b_mfma<agpr, FIRST>(acc[G], a[0], b[0]);
         w4b_gap<NT, FI, 6 * J + 1>(n, vlane, vlane1, m1);
         w4b_mfma<agpr>(acc[G], a[0], b[1]);
         w4b_gap<NT, FI, 6 * J + 2>(n, vlane, vlane1, m1);
@@ -309,7 +393,7 @@ __device__ __forceinline__ void w4b_groups(f32x16 (&acc)[9 * NT], u32x4 (&a)[3],
         } else {
             w4b_gap<NT, FI, 6 * J + 6>(n, vlane, vlane1, m1);
         }
-        w4b_groups<NT, G + 1>(acc, a, n, bv, vlane, vlane1, b_voff, b_chunk, m1);
+        w4b_groups<NT, G + 1, FIRST>(acc, a, n, bv, vlane, vlane1, b_voff, b_chunk, m1);
     }
 }
 // 1-D input transform as w4_bt_store, with staging piece pb + i of the next chunk riding behind the i-th store (i < np), one at
@@ -342,14 +426,17 @@ __device__ __forceinline__ void w4b_bt_store_staging(f32x4 (&d)[6], float* dst, 
 
 template <int NT, bool BNRED = false, bool BF3 = false>
 __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc d, const Wino43Geom g) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // V | raw | slot tables | .. | red ; M aliases V .. red
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // V | raw | two slot tables | red ; the epilogue's M aliases V only
     constexpr int RAW0 = BF3 ? W4B_RAW_B / 4 : W4_VF;                   // float offset of the raw halo
-    float* const rawbase = lds + RAW0;
-    // fp32 form: [640][4] source byte offset of (slot s, channel quad q) (clamped) and [640][4] slot-inside-image flags;
-    // bf16 x 3 form: one entry per slot, [640] offsets then [640] flags, and two raw buffers (chunk c reads buffer c & 1)
-    int* const tab_off = reinterpret_cast<int*>(lds + (BF3 ? W4B_TAB_B / 4 : W4_TAB));
-    int* const tab_ok = BF3 ? tab_off + 640 : reinterpret_cast<int*>(lds + W4_TABOK);
-    float* const red = lds + W4_RED;
+    // Slot tables: source byte offset of every pixel slot of the 18 x 34 halo.  fp32 form: [640][4] (slot s, channel quad q); bf16 x 3
+    // form: one entry per slot (the lane adds its quad) and two raw buffers.  A slot outside the image (and the padding slots >= 612)
+    // has BIT 31 of its offset set: out of range against num_records = 0x7fffffff for every scalar offset, and the LDS-DMA unit
+    // writes ZEROS for an out-of-range lane (tools/micro/dma_oob.hip) -- the padding of the convolution costs no flags and no pass
+    // over the landed halo.  Two tables: the persistent workgroup stages the first chunk of its NEXT region during the last
+    // contraction of the current one, from that region's table.
+    constexpr int TABN = BF3 ? 640 : W4_TABF;                            // ints per table
+    int* const tab_base = reinterpret_cast<int*>(lds + (BF3 ? W4B_TAB_B / 4 : W4_TAB));
+    float* const red = lds + (BF3 ? W4B_RED_B / 4 : W4_RED);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -357,71 +444,49 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    const int bid = blockIdx.x;
-    W4_STAMP(0);
-#ifdef W4_PROF
-    if (tid == 0 && bid < 16384) {
-        w4_prof_buf[bid * 32 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
-        w4_prof_buf[bid * 32 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
-    }
-#endif
-    const int q = bid >> 3;
-    const int cg = q % g.ncog;
-    const int region = (q / g.ncog) * 8 + (bid & 7);
-    if (region >= g.nregions) return;
-    int rr = region;
-    const int tx = rr % g.tiles_x;
-    rr /= g.tiles_x;
-    const int ty = rr % g.tiles_y;
-    const int n = rr / g.tiles_y;
-    const int oy0 = ty * 16, ox0 = tx * 32;
-    const int co0 = cg * 32 * NT;
-
-    // ------------------------------------------------------------------ slot tables: slot s = row*34 + {9,9,8,8 per plane}
+    // ------------------------------------------------------------------ persistent workgroup: virtual block ids v = blockIdx.x + k gridDim.x
+    // (gridDim.x is a multiple of 8: v & 7 = the XCD, as for a plain launch).  v -> (output-channel group, region) as before.
+    int v = blockIdx.x;
+    auto region_of = [&](int vb, int& cgo) {
+        const int q = vb >> 3;
+        cgo = q % g.ncog;
+        return (q / g.ncog) * 8 + (vb & 7);
+    };
     const int xcs = d.in_cstride * 4;
-    const bool interior = oy0 >= 1 && oy0 + 17 <= d.IH && ox0 >= 1 && ox0 + 33 <= d.IW;
-    for (int s = tid; s < 640; s += 256) {
-        const int sc = s < W4_SLOTS ? s : W4_SLOTS - 1;
-        const int row = sc / W4_ROWSLOTS, rem = sc - row * W4_ROWSLOTS;
-        const int plane = rem < 9 ? 0 : (rem < 18 ? 1 : (rem < 26 ? 2 : 3));
-        const int idx = rem - (plane == 0 ? 0 : (plane == 1 ? 9 : (plane == 2 ? 18 : 26)));
-        const int iy = oy0 - 1 + row, ix = ox0 - 1 + 4 * idx + plane;
-        const int iyc = adh_min_i(adh_max_i(iy, 0), d.IH - 1), ixc = adh_min_i(adh_max_i(ix, 0), d.IW - 1);
-        const int off = (iyc * d.IW + ixc) * xcs;
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        const int ok = (s < W4_SLOTS && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) ? 1 : 0;
-        if constexpr (BF3) {
-            tab_off[s] = off;
-            tab_ok[s] = ok;
-        } else {
-            *reinterpret_cast<i32x4*>(tab_off + 4 * s) = i32x4{off, off + 16, off + 32, off + 48};
-            *reinterpret_cast<i32x4*>(tab_ok + 4 * s) = i32x4{ok, ok, ok, ok};
+    auto build_table = [&](int* tab, int oy0, int ox0) {   // slot s = row*34 + {9,9,8,8 per plane}
+        for (int s = tid; s < 640; s += 256) {
+            const int sc = s < W4_SLOTS ? s : W4_SLOTS - 1;
+            const int row = sc / W4_ROWSLOTS, rem = sc - row * W4_ROWSLOTS;
+            const int plane = rem < 9 ? 0 : (rem < 18 ? 1 : (rem < 26 ? 2 : 3));
+            const int idx = rem - (plane == 0 ? 0 : (plane == 1 ? 9 : (plane == 2 ? 18 : 26)));
+            const int iy = oy0 - 1 + row, ix = ox0 - 1 + 4 * idx + plane;
+            const int iyc = adh_min_i(adh_max_i(iy, 0), d.IH - 1), ixc = adh_min_i(adh_max_i(ix, 0), d.IW - 1);
+            const bool ok = s < W4_SLOTS && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
+            const int off = ((iyc * d.IW + ixc) * xcs) | (ok ? 0 : (int)0x80000000);
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            if constexpr (BF3) tab[s] = off;
+            else *reinterpret_cast<i32x4*>(tab + 4 * s) = i32x4{off, off + 16, off + 32, off + 48};
         }
-    }
-    const float* in_n = d.in + (int64_t)n * d.IH * d.IW * d.in_cstride;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, 0x7fffffff, 0x00020000);
+    };
+    // (image as a uniform POINTER, made a resource where it is used: hipcc selects between two buffer resources in VGPRs, and
+    // every LDS-DMA piece that takes the result becomes a waterfall loop)
+    auto image_ptr = [&](int n) { return d.in + (int64_t)n * d.IH * d.IW * d.in_cstride; };
+    auto image_rsrc = [&](const float* in_n) {
+        const uint64_t a = reinterpret_cast<uint64_t>(in_n);
+        const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(u), 0, 0x7fffffff, 0x00020000);
+    };
     const int cq_l = lane & 3;
-    // 40 pieces per chunk, 10 per wave: piece k = 4u + wave covers slots 16k..16k+15 (slots >= 612 repeat slot 611); lane l of
-    // piece k loads (slot 16k + l / 4, quad l % 4): its table entry is tab_off[64 k + l], i.e. one contiguous read per piece
+    // 40 pieces per chunk, 10 per wave: piece k = 4u + wave covers slots 16k..16k+15; lane l of piece k loads (slot 16k + l / 4,
+    // quad l % 4): its table entry is tab[64 k + l], i.e. one contiguous read per piece
+    // (bf16 x 3 form: piece k = 4u + wave, lane l stages slot 16k + l / 4: entry tab[64 u + 16 wave + l / 4], + 16 (l % 4) bytes)
+    const int tab_lane_o = BF3 ? 16 * wave + (lane >> 2) : 64 * wave + lane;   // this lane's entry of piece 0 inside a table
     W4Stage st;
-    st.rsrc = xr;
-    // (bf16 x 3 form: piece k = 4u + wave, lane l stages slot 16k + l / 4: entry tab_off[64 u + 16 wave + l / 4], + 16 (l % 4) bytes)
-    st.tab_lane = BF3 ? tab_off + 16 * wave + (lane >> 2) : tab_off + 64 * wave + lane;
     st.lds = lds;
     st.lds_wave = __builtin_amdgcn_readfirstlane((RAW0 + wave * 256) * 4);
     st.cb = 0;
     constexpr int TABU = BF3 ? 64 : 256;          // table entries between two pieces of a wave
     const int quad16_o = (lane & 3) * 16;
-    auto stage_first = [&]() {   // chunk 0 (prologue); the later chunks arrive piece by piece inside the contraction
-        int vo[10];   // all table reads first: one LDS round trip instead of ten
-#pragma unroll
-        for (int u = 0; u < 10; ++u) vo[u] = st.tab_lane[TABU * u] + (BF3 ? quad16_o : 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 10; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + u * 4096), 16,
-                                                     vo[u], 0, 0, 0);
-    };
     // bf16 x 3 form: next to 27 accumulator tiles, the weight ring and the planes in the making, the contraction has fewer than ten
     // registers to spare: nothing a thread needs only OUTSIDE the contraction may stay live across it.  Such per-thread constants are
     // rebuilt from v_mbcnt where they are used (the asm keeps hipcc from hoisting the rebuild back out of the chunk loop).
@@ -429,16 +494,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(l));
         return l;
-    };
-    auto fix_raw = [&](int buf = 0) {   // (bf16 x 3 form: buf = the raw buffer just staged)
-        if (interior) return;
-        const int ln = BF3 ? lane_rebuilt() : lane;
-        const int* const tabl = BF3 ? tab_off + 16 * wave + (ln >> 2) : st.tab_lane;
-        float* raw = rawbase + buf * (W4B_RAWBUF_B / 4) + wave * 256 + ln * 4;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 10; ++u)
-            if (!tabl[(BF3 ? 640 : 4 * 640) + TABU * u]) *reinterpret_cast<f32x4*>(raw + u * 1024) = z;
     };
 
     // ------------------------------------------------------------------ input transform (two 1-D passes through LDS)
@@ -455,9 +510,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const int raw_k1_o = (RAW0 + rbase_t) / 4 + (csel ? 26 : 18) * 4;    // address space: flat loads; an opaque float index the alignment: b32 reads)
     const W4Neg negc = w4_neg_constants();
     constexpr int p2n = BF3 ? 0 : w4_p2_pieces();   // pieces of the next chunk's halo issued during pass 2 (fp32 form, dev option)
-    auto transform = [&](int cbuf) {   // cbuf (bf16 x 3 form) = c & 1: the raw buffer this chunk reads; the other one is staged
+    // cbuf (bf16 x 3 form) = the raw buffer this chunk reads; the other one is staged from table `stab` (st.rsrc / st.cb: image and
+    // channel offset of what is staged -- the next chunk of this region or the first chunk of the next one)
+    auto transform = [&](int cbuf, const int* stab) {
         int vslot_t = vslot_o, raw_k0 = raw_k0_o, raw_k1 = raw_k1_o, quad16 = quad16_o;
-        const int* tabl = st.tab_lane;
+        const int* tabl = stab + tab_lane_o;
         if constexpr (BF3) {   // (see lane_rebuilt)
             const int ln = lane_rebuilt();
             const int tl = ((wave & 1) << 4) | (ln >> 2), cq = ln & 3;
@@ -466,7 +523,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             raw_k0 = (RAW0 + rb) / 4 + (csel ? 9 : 0) * 4;
             raw_k1 = (RAW0 + rb) / 4 + (csel ? 26 : 18) * 4;
             quad16 = cq * 16;
-            tabl = tab_off + 16 * wave + (ln >> 2);
+            tabl = stab + 16 * wave + (ln >> 2);
         }
         // pass 1: T[a][c] = sum_i B^T[a][i] d[i][c] for this thread's three columns c = csel, 2 + csel, 4 + csel
 #pragma unroll
@@ -536,16 +593,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     const float* const vlane1 = lds + (wave * 9) * (W4_TILES * W4_KC) + l31 * 16 + (((2 + h) ^ sw) * 4);   // g = 1
     // B: U[f][kq = 4c + 2g + h][n = co0 + 32 j + l31] (float4)
     const unsigned b_voff = (unsigned)((h * d.NcP + l31) * 16);
-    const float* const b_wave = d.wp + ((int64_t)(wave * 9) * g.KQtot * d.NcP + co0) * 4;
     const int64_t b_fstride = (int64_t)g.KQtot * d.NcP * 4;   // floats per frequency
     const int b_kq = d.NcP * 4;                                // floats per channel quad
-
     // bf16 x 3 form.  A: the same two 16-byte reads per frequency (the lane's tile, channel quads h and 2 + h), split in registers.
     // B: adh_pack_weights_wino43_bf16x3's [cog][chunk][36 f][NT][3 planes][64 lanes][16 B]: the 9 NT groups of a wave and chunk
     // are 27 NT KB contiguous, lane offset 16 * lane
     const unsigned b3_voff = (unsigned)lane * 16u;
     const size_t b3_cstride = (size_t)36 * NT * 3072;                                   // bytes of U per chunk and channel group
-    const char* const b3_wave = reinterpret_cast<const char*>(d.wp) + ((size_t)cg * g.nchunks * 36 + (size_t)wave * 9) * (NT * 3072);
 
     f32x16 acc[9 * NT];
     f32x4 av[2], bv[3][NT];
@@ -553,265 +607,350 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     W4BNext nx;
     const float m1s = adh_opaque(-1.f);
 
-    // ------------------------------------------------------------------ prologue
-    __syncthreads();   // slot tables
-    if constexpr (!BF3) {
-        w4_load_b<NT>(bv[0], b_voff, b_wave);
-        w4_load_b<NT>(bv[1], b_voff, b_wave + b_fstride);
+    // ------------------------------------------------------------------ prologue of the workgroup: table and first chunk of its first region
+    int cg, region = region_of(v, cg);
+    if (region >= g.nregions) return;
+    {
+        int rr = region;
+        const int tx = rr % g.tiles_x;
+        rr /= g.tiles_x;
+        const int ty = rr % g.tiles_y;
+        const int n = rr / g.tiles_y;
+        build_table(tab_base, ty * 16, tx * 32);
+        st.rsrc = image_rsrc(image_ptr(n));
     }
-    stage_first();
+    W4_STAMP(0);
+    __syncthreads();   // slot table
+    {   // chunk 0 of the first region; the later chunks (and regions) arrive piece by piece inside the main loop
+        int vo[10];   // all table reads first: one LDS round trip instead of ten
 #pragma unroll
-    for (int t = 0; t < 9 * NT; ++t)   // (zeroing 9*NT*16 registers hides under the first DMA round trip)
+        for (int u = 0; u < 10; ++u) vo[u] = tab_base[tab_lane_o + TABU * u] + (BF3 ? quad16_o : 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fix_raw();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+        for (int u = 0; u < 10; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + u * 4096), 16,
+                                                     vo[u], 0, 0, 0);
+    }
+    int cpar = 0;      // bf16 x 3 form: the raw buffer the next transform reads (toggles per chunk, across regions)
+    int tsel = 0;      // which table is this region's
 
-    W4_STAMP(1);
 #pragma unroll 1
-    for (int c = 0; c < g.nchunks; ++c) {
-        const bool more = c + 1 < g.nchunks;
-        const int cn = more ? c + 1 : c;   // the last chunk re-stages itself (uniform counts)
-        // ---- transform raw(c) -> V (every wave is past the previous chunk's contraction: barrier at the loop end)
-        st.cb = cn * (W4_KC * 4);
-        if (c == 1) W4_STAMP(8);
-        if (c == 1) W4_STAMP(9);
-        if (!(W4_DBG & 1)) transform(c & 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (c == 1) W4_STAMP(10);
-        if constexpr (BF3) {   // the weights of groups 0 and 1: on their way during the barrier and the first frequency's split
-            if (!(W4_DBG & 2)) {
-                w4b_load_b(bv3[0], b3_voff, b3_wave + c * b3_cstride);
-                w4b_load_b(bv3[1], b3_voff, b3_wave + c * b3_cstride + 3072);
-            }
+    for (int it = 0;; ++it) {
+#ifdef W4_PROF
+        if (it) W4_STAMP(0);
+        if (tid == 0 && v < 16384) {
+            w4_prof_buf[v * 32 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+            w4_prof_buf[v * 32 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
         }
-        __builtin_amdgcn_s_barrier();
-        if (c == 1) W4_STAMP(11);
-        // ---- contraction.  In flight: the weights of groups 0 and 1 and, newer, the pieces pass 2 issued.  The raw buffer is
-        // free from pass 2 to the end of the contraction (its only reader is pass 1), so the next chunk's halo lands in it
-        // meanwhile; the weight waits of the later groups retire the pieces in order
-        if constexpr (BF3) {
-            if (!(W4_DBG & 2)) {
-                // the planes of the wave's first frequency, split while the first weights are on their way; then the values of the second
-                w4b_load_s(nx, vlane, vlane1);
-                w4b_steps<0, 20>(nx, m1s);
-                av3[0] = u32x4{nx.h[0], nx.h[1], nx.h[2], nx.h[3]};
-                av3[1] = u32x4{nx.m[0], nx.m[1], nx.m[2], nx.m[3]};
-                av3[2] = u32x4{nx.l[0], nx.l[1], nx.l[2], nx.l[3]};
-                asm volatile("s_nop 1" : "+v"(av3[0]), "+v"(av3[1]), "+v"(av3[2]));
-                w4b_load_s(nx, vlane + W4_TILES * W4_KC, vlane1 + W4_TILES * W4_KC);
-                __builtin_amdgcn_sched_barrier(0);
-                w4b_groups<NT, 0>(acc, av3, nx, bv3, vlane, vlane1, b3_voff, b3_wave + c * b3_cstride, m1s);
-            }
-        } else if (!(W4_DBG & 2)) {
-            const float* b_chunk = b_wave + (int64_t)(c * 4) * b_kq;
-            const float* b_next = b_wave + (int64_t)(cn * 4) * b_kq;
-            av[0] = *reinterpret_cast<const f32x4*>(vlane);
-            // group 0
-            w4_load_b<NT>(bv[2], b_voff, b_chunk + 2 * b_fstride);
-            av[1] = *reinterpret_cast<const f32x4*>(vlane + 1 * (W4_TILES * W4_KC));
-            w4_wait_b<2 * NT + w4_p2_pieces(), NT>(bv[0]);
-            w4_group<NT, 0, 0, 0>(acc, av[0], bv[0]);
-            // group 1
-            w4_load_b<NT>(bv[0], b_voff, b_chunk + 3 * b_fstride);
-            av[0] = *reinterpret_cast<const f32x4*>(vlane + 2 * (W4_TILES * W4_KC));
-            w4_wait_b<2 * NT + w4_p2_pieces(), NT>(bv[1]);
-            w4_group<NT, 1, 0, 0>(acc, av[1], bv[1]);
-            // groups 2..17
-            w4_chunk<NT, 2>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, 2 * b_kq, st);
+#endif
+        int rr = region;
+        const int tx = rr % g.tiles_x;
+        rr /= g.tiles_x;
+        const int ty = rr % g.tiles_y;
+        const int n = rr / g.tiles_y;
+        const int oy0 = ty * 16, ox0 = tx * 32;
+        const int co0 = cg * 32 * NT;
+        const float* const in_cur = image_ptr(n);
+        int* const tab_cur = tab_base + tsel * TABN;
+        int* const tab_nxt = tab_base + (tsel ^ 1) * TABN;
+        // the next region of this workgroup (regions grow with v: the first invalid one ends the list)
+        const int vn = v + (int)gridDim.x;
+        int cgn = 0, regn = 0;
+        bool has_next = vn < g.nvblocks;
+        if (has_next) {
+            regn = region_of(vn, cgn);
+            has_next = regn < g.nregions;
         }
-        if (c == 1) W4_STAMP(12);
-        fix_raw(BF3 ? ((c + 1) & 1) : 0);
+        const float* in_next = in_cur;
+        if (has_next) {   // its table (the buffer's last reader was the previous region's main loop) and image
+            int r2 = regn;
+            const int tx2 = r2 % g.tiles_x;
+            r2 /= g.tiles_x;
+            build_table(tab_nxt, (r2 % g.tiles_y) * 16, tx2 * 32);
+            in_next = image_ptr(r2 / g.tiles_y);
+        }
+        W4_STAMP(4);
+        const float* const b_wave = d.wp + ((int64_t)(wave * 9) * g.KQtot * d.NcP + co0) * 4;
+        const char* const b3_wave = reinterpret_cast<const char*>(d.wp) + ((size_t)cg * g.nchunks * 36 + (size_t)wave * 9) * (NT * 3072);
+        if constexpr (!BF3) {   // the weights of groups 0 and 1: on their way during the first transform
+            w4_load_b<NT>(bv[0], b_voff, b_wave);
+            w4_load_b<NT>(bv[1], b_voff, b_wave + b_fstride);
+        }
+        W4_STAMP(5);
+#pragma unroll
+        for (int t = 0; t < 9 * NT; ++t)   // (~0.9 us per region.  Tried: the first chunk's first MFMA on every tile with C = 0 instead -- a second
+#pragma unroll                             // instantiation of the contraction behind `if (c == 0)`: hipcc then spills ~700 registers.)
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // first region: its halo was requested above; later regions: it landed during the previous region's last contraction and
+        // was waited for (vmcnt(0)) in front of that region's epilogue barriers
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (c == 1) W4_STAMP(13);
-    }
-    if constexpr (!BF3) {
-        w4_wait_b<0, NT>(bv[0]);
-        w4_wait_b<0, NT>(bv[1]);
-    }
-    W4_STAMP(2);
+        __builtin_amdgcn_s_barrier();   // halo and the next region's table visible
 
-    // ---------------------------------------------------------------------- output transform A^T M A + fused epilogue
-    // One output-channel tile (32 co) at a time: accumulators -> M[36][32 tile rows][32 co] in LDS (tile t sits in row
-    // t' = t with its low three bits rotated so that the two lane halves, tiles t and t + 4, hit different banks), then
-    // thread = (tile, channel quad): float4 reads of its 6x6 frequency patch, A^T m A in two halves (output rows 0-1,
-    // 2-3: 12 + 6 float4 live next to the accumulators still waiting), 16 B stores.
-    if (W4_DBG & 4) return;
-    float* M = lds;   // spans V and the raw buffers
-    const int et = tid >> 3, eq = tid & 7;
-    const int etp = (et & ~7) | ((et & 3) << 1) | ((et >> 2) & 1);
-    const int ey0 = oy0 + 4 * (et >> 3), ex0 = ox0 + 4 * (et & 7);
-    // One code path for full and ragged regions, without per-pixel address arithmetic or exec-mask branches: raw buffer
-    // stores / residual loads whose address is a per-thread byte offset (constant for the region) plus a workgroup-uniform
-    // scalar offset per pixel.  A pixel outside the image or a channel quad beyond Cout gets bit 31 of its vector offset set.  The hardware's range check is
-    // `vector offset >= num_records - scalar offset` (unsigned), so with num_records = 0x7fffffff such an access is out
-    // of range for every scalar offset (the store is dropped, the load returns zeros), while a real access, whose byte
-    // offset inside the image is below 2^31 (wino43_plan), never is.  (An exact num_records would be wrong here: with a
-    // scalar offset above it the subtraction wraps and nothing is checked.)
-    float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
-    const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
-    const int o_px = d.out_cstride * 4, o_row = d.OW * o_px;       // byte pitches (workgroup-uniform)
-    const int r_px = d.res_cstride * 4, r_row = d.OW * r_px;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_n, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res_n ? res_n : out_n), 0, 0x7fffffff, 0x00020000);
-    const bool ragged = oy0 + 16 > d.OH || ox0 + 32 > d.OW;     // workgroup-uniform
-    const float act_lo = d.act == ADH_ACT_RELU ? 0.f : -INFINITY;   // ReLU as max(v, 0), identity as max(v, -inf)
-    unsigned rowpen[4], colpen[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        rowpen[r] = ey0 + r < d.OH ? 0u : 0x80000000u;
-        colpen[r] = ex0 + r < d.OW ? 0u : 0x80000000u;
-    }
-    const unsigned o_vbase = (unsigned)((ey0 * d.OW + ex0) * o_px + (co0 + eq * 4) * 4);
-    const unsigned r_vbase = (unsigned)((ey0 * d.OW + ex0) * r_px + (co0 + eq * 4) * 4);
-    const unsigned m_wbase = (unsigned)(((wave * 9) * W4_TILES + h) * 32 + l31) * 4u;   // byte address of M[9 wave][h][l31]
-    const float* const mp = M + etp * 32 + eq * 4;
-    const float m1 = adh_opaque(-1.f);
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        if (j == 1) W4_STAMP(16);
-        __builtin_amdgcn_s_barrier();   // V / raw (first tile) or the previous tile's M fully consumed
-        if (j == 1) W4_STAMP(17);
-        if (j == 0) w4_store_m<NT, 0, 0, 0>(acc, m_wbase);
-        if (j == 1) w4_store_m<NT, (NT > 1 ? 1 : 0), 0, 0>(acc, m_wbase);
-        if (j == 2) w4_store_m<NT, (NT > 2 ? 2 : 0), 0, 0>(acc, m_wbase);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (j == 1) W4_STAMP(18);
-        __builtin_amdgcn_s_barrier();
-        if (j == 1) W4_STAMP(19);
-        const int cq0 = co0 + j * 32 + eq * 4;
-        const bool quad_ok = cq0 + 3 < d.Cout;             // Cout % 4 == 0 (wino43_plan): a quad is real or padding
-        f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-        if (d.scale && quad_ok) sc4 = *reinterpret_cast<const f32x4*>(d.scale + cq0);
-        if (d.shift && quad_ok) sh4 = *reinterpret_cast<const f32x4*>(d.shift + cq0);
-        f32x4 mean4 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (BNRED) {
-            if (quad_ok) mean4 = *reinterpret_cast<const f32x4*>(g.bn_mean + cq0);
-        }
-        const unsigned chanpen = quad_ok ? 0u : 0x80000000u;
-        const unsigned o_vj = (o_vbase + j * 128) | chanpen, r_vj = (r_vbase + j * 128) | chanpen;
-        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (j == 1 && half == 1) W4_STAMP(20);
-            f32x4 u[2][6];
-            f32x4 rres[8];   // the residual of this half's 2 x 4 pixels, in flight during the transform
-            if (res_n) {   // workgroup-uniform; the asm keeps it a branch (the zero-initialised alternative is free)
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        rres[ii * 4 + jj] = __builtin_bit_cast(
-                            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, r_vj | rowpen[2 * half + ii] | colpen[jj],
-                                                                         (2 * half + ii) * r_row + jj * r_px, 0));
-                asm volatile("" ::: "memory");
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) rres[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                f32x4 m[6];
-#pragma unroll
-                for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(mp + (a * 6 + b) * (W4_TILES * 32));
-                const f32x4 s12 = m[1] + m[2], d12 = adh_pksub(m[1], m[2], m1), s34 = m[3] + m[4], d34 = adh_pksub(m[3], m[4], m1);
-                if (half == 0) {   // rows of A^T: [1 1 1 1 1 0], [0 a -a b -b 0], [0 a^2 a^2 b^2 b^2 0], [0 a^3 -a^3 b^3 -b^3 1]
-                    u[0][b] = m[0] + s12 + s34;
-                    u[1][b] = W4_A * d12 + W4_B * d34;
-                } else {
-                    u[0][b] = W4_A2 * s12 + W4_B2 * s34;
-                    u[1][b] = W4_A3 * d12 + W4_B3 * d34 + m[5];
+        W4_STAMP(1);
+#pragma unroll 1
+        for (int c = 0; c < g.nchunks; ++c) {
+            const bool more = c + 1 < g.nchunks;
+            // what this chunk stages: the next chunk of this region, or -- last chunk -- the first chunk of the next region (from its
+            // table and image); the very last chunk of the workgroup re-stages itself (uniform counts)
+            const bool cross = !more && has_next;
+            st.cb = more ? (c + 1) * (W4_KC * 4) : (cross ? 0 : c * (W4_KC * 4));
+            st.rsrc = image_rsrc(cross ? in_next : in_cur);
+            const int* const stab = cross ? tab_nxt : tab_cur;
+            st.tab_lane = stab + tab_lane_o;
+            // ---- transform raw(c) -> V (every wave is past the previous chunk's contraction: barrier at the loop end)
+            if (c == 1) W4_STAMP(8);
+            if (c == 1) W4_STAMP(9);
+            if (!(W4_DBG & 1)) transform(cpar, stab);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (c == 1) W4_STAMP(10);
+            if constexpr (BF3) {   // the weights of groups 0 and 1: on their way during the barrier and the first frequency's split
+                if (!(W4_DBG & 2)) {
+                    w4b_load_b(bv3[0], b3_voff, b3_wave + c * b3_cstride);
+                    w4b_load_b(bv3[1], b3_voff, b3_wave + c * b3_cstride + 3072);
                 }
             }
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const f32x4 s12 = u[ii][1] + u[ii][2], d12 = adh_pksub(u[ii][1], u[ii][2], m1), s34 = u[ii][3] + u[ii][4],
-                            d34 = adh_pksub(u[ii][3], u[ii][4], m1);
-                const f32x4 y[4] = {u[ii][0] + s12 + s34, W4_A * d12 + W4_B * d34, W4_A2 * s12 + W4_B2 * s34,
-                                    W4_A3 * d12 + W4_B3 * d34 + u[ii][5]};
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    if constexpr (BNRED) {
-                        // data-gradient launch that also takes the PRODUCING layer's BatchNorm-backward sums:
-                        // the output is that layer's output gradient g; `residual` is its raw convolution output y, scale /
-                        // shift its forward BN scale / shift, so m = [fma(y, scale, shift) > 0] is its ReLU mask (the forward
-                        // expression of bn_apply_kernel, bit for bit); statistics rows = sum g m, sum g m (y - mean).  g is stored as is.
-                        const f32x4 yv = rres[ii * 4 + jj];
-                        // a pixel outside the image / a padding channel quad has bit 31 of its store offset set: it does not count
-                        // (no per-pixel float masks: eight more live registers spill 80 here)
-                        const unsigned oaddr = o_vj | rowpen[2 * half + ii] | colpen[jj];
-                        const bool inside = (int)oaddr >= 0;
-                        f32x4 gm;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) gm[e] = (inside && __builtin_fmaf(yv[e], sc4[e], sh4[e]) > 0.f) ? y[jj][e] : 0.f;
-                        ssum += gm;
-                        ssq += gm * adh_pksub(yv, mean4, m1);
-                        f32x4 v = y[jj];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, oaddr,
-                                                               (2 * half + ii) * o_row + jj * o_px, W_STORE_AUX);
-                        asm volatile("s_nop %1" : "+v"(v) : "n"(W4_STORE_NOPS) : "memory");
-                        continue;
-                    }
-                    f32x4 v = y[jj] * sc4 + sh4;
-                    if (d.stats) {
-                        f32x4 vs = v;
-                        if (ragged) {   // pixels outside the image do not count (a real, workgroup-uniform branch: the asm keeps
-                            // the compiler from turning it into selects); bit 31 of the store offset marks them
-                            const bool inside = (int)(o_vj | rowpen[2 * half + ii] | colpen[jj]) >= 0;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) vs[e] = inside ? v[e] : 0.f;
-                            asm volatile("" : "+v"(vs));
-                        }
-                        ssum += vs;
-                        ssq += vs * vs;
-                    }
-                    v += rres[ii * 4 + jj];      // zeros without a residual
-                    v = {fmaxf(v[0], act_lo), fmaxf(v[1], act_lo), fmaxf(v[2], act_lo), fmaxf(v[3], act_lo)};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc,
-                                                           o_vj | rowpen[2 * half + ii] | colpen[jj],
-                                                           (2 * half + ii) * o_row + jj * o_px, W_STORE_AUX);
-                    // gfx950: a 128-bit buffer store whose data VGPRs are overwritten by the very next instructions stores
-                    // the NEW values in some lanes (lanes 12-15 of every 16) even when its soffset is an SGPR (measured:
-                    // tools/dev_w43_probe.py, tools/dev_w32_probe.py; LLVM pads only the immediate-soffset form,
-                    // GCNHazardRecognizer "12-dword store hazard", and schedules such an overwrite right behind the store).
-                    // The asm reads the data registers, so they stay untouched until its wait states have passed.
-                    asm volatile("s_nop %1" : "+v"(v) : "n"(W4_STORE_NOPS) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c == 1) W4_STAMP(11);
+            // ---- contraction.  In flight: the weights of groups 0 and 1 and, newer, the pieces pass 2 issued.  The raw buffer is
+            // free from pass 2 to the end of the contraction (its only reader is pass 1), so the next chunk's halo lands in it
+            // meanwhile; the weight waits of the later groups retire the pieces in order
+            if constexpr (BF3) {
+                if (!(W4_DBG & 2)) {
+                    // the planes of the wave's first frequency, split while the first weights are on their way; then the values of the second
+                    w4b_load_s(nx, vlane, vlane1);
+                    w4b_steps<0, 20>(nx, m1s);
+                    av3[0] = u32x4{nx.h[0], nx.h[1], nx.h[2], nx.h[3]};
+                    av3[1] = u32x4{nx.m[0], nx.m[1], nx.m[2], nx.m[3]};
+                    av3[2] = u32x4{nx.l[0], nx.l[1], nx.l[2], nx.l[3]};
+                    asm volatile("s_nop 1" : "+v"(av3[0]), "+v"(av3[1]), "+v"(av3[2]));
+                    w4b_load_s(nx, vlane + W4_TILES * W4_KC, vlane1 + W4_TILES * W4_KC);
+                    __builtin_amdgcn_sched_barrier(0);
+                    w4b_groups<NT, 0, W4_ZERO_C>(acc, av3, nx, bv3, vlane, vlane1, b3_voff, b3_wave + c * b3_cstride, m1s);
                 }
+            } else if (!(W4_DBG & 2)) {
+                const int cn = more ? c + 1 : c;   // (the last chunk requests its own first weights again: drained below)
+                const float* b_chunk = b_wave + (int64_t)(c * 4) * b_kq;
+                const float* b_next = b_wave + (int64_t)(cn * 4) * b_kq;
+                w4_contract<NT, W4_ZERO_C>(acc, av, bv, vlane, vlane1, b_voff, b_chunk, b_next, b_fstride, b_kq, st);
             }
-        }
-        if (j == 1) W4_STAMP(21);
-        if (d.stats) {
-            // sum over the 8 tiles of this wave (lane bits 3..5), then over the 4 waves through LDS
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    ssum[e] += __shfl_xor(ssum[e], o, 64);
-                    ssq[e] += __shfl_xor(ssq[e], o, 64);
-                }
-            }
-            if (j) __builtin_amdgcn_s_barrier();
-            if (lane < 8) {
-                *reinterpret_cast<f32x4*>(red + (0 * 4 + wave) * 32 + eq * 4) = ssum;
-                *reinterpret_cast<f32x4*>(red + (1 * 4 + wave) * 32 + eq * 4) = ssq;
-            }
+            if (c == 1) W4_STAMP(12);
+            cpar ^= 1;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (tid < 64) {
-                const int which = tid >> 5, cl = tid & 31;
-                float v = 0.f;
+            if (c == 1) W4_STAMP(13);
+        }
+        // everything this wave requested has landed: the weights re-requested by the last chunk and, above all, its pieces of the
+        // next region's first chunk -- the epilogue's barriers make them visible to the other waves
+        if constexpr (!BF3) {
+            w4_wait_b<0, NT>(bv[0]);
+            w4_wait_b<0, NT>(bv[1]);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        W4_STAMP(2);
+
+        // ---------------------------------------------------------------------- output transform A^T M A + fused epilogue
+        // Six rounds: one output-channel tile (32 co) and one half of the region (16 tiles = two tile rows = accumulator registers
+        // 8 th .. 8 th + 7) at a time: accumulators -> M[36][16 tiles][32 co] in LDS -- exactly V's 72 KB, so the raw halo of the next
+        // region and the tables stay intact -- (tile t sits in row t' = t with its low three bits rotated so that the two lane halves,
+        // tiles t and t + 4, hit different banks), then thread = (tile row t', channel quad, output-row half rh = wave >> 1): float4
+        // reads of its 6 x 6 frequency patch, the two rows 2 rh, 2 rh + 1 of A^T m A, 16-byte stores.  The M write of round r + 1 is
+        // issued between the column pass of round r (the last reader of M) and its row pass: the LDS drains it under the row pass's
+        // VALU work and stores, and the accumulator registers it frees are dead before the row pass needs its own.
+        if (!(W4_DBG & 4)) {
+            float* M = lds;
+            const int etp = (tid >> 3) & 15, eq = tid & 7;
+            const int rh = wave >> 1;                                         // wave-uniform: rows 2 rh, 2 rh + 1 of every tile
+            const int et = (etp & 8) | ((etp & 1) << 2) | ((etp >> 1) & 3);   // the tile (of its half) in row etp
+            const int ey0 = oy0 + 4 * (et >> 3) + 2 * rh, ex0 = ox0 + 4 * (et & 7);    // region half 0; half 1 sits 8 rows below
+            // One code path for full and ragged regions, without per-pixel address arithmetic or exec-mask branches: raw buffer
+            // stores / residual loads whose address is a per-thread byte offset (constant for the region) plus a workgroup-uniform
+            // scalar offset per pixel.  A pixel outside the image or a channel quad beyond Cout gets bit 31 of its vector offset set.  The hardware's range check is
+            // `vector offset >= num_records - scalar offset` (unsigned), so with num_records = 0x7fffffff such an access is out
+            // of range for every scalar offset (the store is dropped, the load returns zeros), while a real access, whose byte
+            // offset inside the image is below 2^31 (wino43_plan), never is.  (An exact num_records would be wrong here: with a
+            // scalar offset above it the subtraction wraps and nothing is checked.)
+            float* out_n = d.out + (size_t)n * d.OH * d.OW * d.out_cstride;
+            const float* res_n = d.residual ? d.residual + (size_t)n * d.OH * d.OW * d.res_cstride : nullptr;
+            const int o_px = d.out_cstride * 4, o_row = d.OW * o_px;       // byte pitches (workgroup-uniform)
+            const int r_px = d.res_cstride * 4, r_row = d.OW * r_px;
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_n, 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rrsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res_n ? res_n : out_n), 0, 0x7fffffff, 0x00020000);
+            const bool ragged = oy0 + 16 > d.OH || ox0 + 32 > d.OW;     // workgroup-uniform
+            const float act_lo = d.act == ADH_ACT_RELU ? 0.f : -INFINITY;   // ReLU as max(v, 0), identity as max(v, -inf)
+            unsigned colpen[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v += red[(which * 4 + r) * 32 + cl];
-                d.stats[((size_t)region * 2 + which) * d.NcP + co0 + j * 32 + cl] = v;
+            for (int r = 0; r < 4; ++r) colpen[r] = ex0 + r < d.OW ? 0u : 0x80000000u;
+            const unsigned o_vbase = (unsigned)((ey0 * d.OW + ex0) * o_px + (co0 + eq * 4) * 4);
+            const unsigned r_vbase = (unsigned)((ey0 * d.OW + ex0) * r_px + (co0 + eq * 4) * 4);
+            const unsigned m_wbase = (unsigned)((wave * 9) * 2048 + h * 128 + l31 * 4);   // byte address of M[9 wave][h][l31]
+            const float* const mp = M + etp * 32 + eq * 4;
+            const float m1 = adh_opaque(-1.f);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            // (V fully consumed: barrier at the end of the last chunk)
+            w4_store_mh<NT, 0>(acc, m_wbase, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int cq0 = co0 + j * 32 + eq * 4;
+                const bool quad_ok = cq0 + 3 < d.Cout;             // Cout % 4 == 0 (wino43_plan): a quad is real or padding
+                f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+                if (d.scale && quad_ok) sc4 = *reinterpret_cast<const f32x4*>(d.scale + cq0);
+                if (d.shift && quad_ok) sh4 = *reinterpret_cast<const f32x4*>(d.shift + cq0);
+                f32x4 mean4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (BNRED) {
+                    if (quad_ok) mean4 = *reinterpret_cast<const f32x4*>(g.bn_mean + cq0);
+                }
+                const unsigned chanpen = quad_ok ? 0u : 0x80000000u;
+                const unsigned o_vj = (o_vbase + j * 128) | chanpen, r_vj = (r_vbase + j * 128) | chanpen;
+                f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int th = 0; th < 2; ++th) {
+                    if (j == 1 && th == 0) W4_STAMP(16);
+                    // ---- column pass: rows 2 rh, 2 rh + 1 of A^T m for the six frequency columns
+                    // rows of A^T: [1 1 1 1 1 0], [0 a -a b -b 0], [0 a^2 a^2 b^2 b^2 0], [0 a^3 -a^3 b^3 -b^3 1]
+                    f32x4 u[2][6];
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {
+                        f32x4 m[6];
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(mp + (a * 6 + b) * (16 * 32));
+                        const f32x4 s12 = m[1] + m[2], d12 = adh_pksub(m[1], m[2], m1), s34 = m[3] + m[4], d34 = adh_pksub(m[3], m[4], m1);
+                        if (rh == 0) {
+                            u[0][b] = m[0] + s12 + s34;
+                            u[1][b] = W4_A * d12 + W4_B * d34;
+                        } else {
+                            u[0][b] = W4_A2 * s12 + W4_B2 * s34;
+                            u[1][b] = W4_A3 * d12 + W4_B3 * d34 + m[5];
+                        }
+                    }
+                    if (j == 1 && th == 0) W4_STAMP(17);
+                    __builtin_amdgcn_s_barrier();   // M fully consumed
+                    if (j == 1 && th == 0) W4_STAMP(18);
+                    // ---- the next round's accumulators go into M during the row pass: frequency 0 now, one more behind every pixel
+                    const int jn = th == 0 ? j : j + 1, thn = th ^ 1;   // the next round (jn == NT: none)
+                    w4_store_mh_round<NT>(acc, m_wbase, jn, thn, 0);
+                    if (j == 1 && th == 0) W4_STAMP(19);
+                    // ---- row pass, fused epilogue, stores
+                    unsigned rowpen[2];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) rowpen[r] = ey0 + 8 * th + r < d.OH ? 0u : 0x80000000u;
+                    f32x4 rres[8];   // the residual of this thread's 2 x 4 pixels
+                    if (res_n) {   // workgroup-uniform; the asm keeps it a branch (the zero-initialised alternative is free)
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                rres[ii * 4 + jj] = __builtin_bit_cast(
+                                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, r_vj | rowpen[ii] | colpen[jj],
+                                                                                 (8 * th + ii) * r_row + jj * r_px, 0));
+                        asm volatile("" ::: "memory");
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) rres[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const f32x4 s12 = u[ii][1] + u[ii][2], d12 = adh_pksub(u[ii][1], u[ii][2], m1), s34 = u[ii][3] + u[ii][4],
+                                    d34 = adh_pksub(u[ii][3], u[ii][4], m1);
+                        const f32x4 y[4] = {u[ii][0] + s12 + s34, W4_A * d12 + W4_B * d34, W4_A2 * s12 + W4_B2 * s34,
+                                            W4_A3 * d12 + W4_B3 * d34 + u[ii][5]};
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const unsigned oaddr = o_vj | rowpen[ii] | colpen[jj];
+                            if constexpr (BNRED) {
+                                // data-gradient launch that also takes the PRODUCING layer's BatchNorm-backward sums:
+                                // the output is that layer's output gradient g; `residual` is its raw convolution output y, scale /
+                                // shift its forward BN scale / shift, so m = [fma(y, scale, shift) > 0] is its ReLU mask (the forward
+                                // expression of bn_apply_kernel, bit for bit); statistics rows = sum g m, sum g m (y - mean).  g is stored as is.
+                                const f32x4 yv = rres[ii * 4 + jj];
+                                // a pixel outside the image / a padding channel quad has bit 31 of its store offset set: it does not count
+                                // (no per-pixel float masks: eight more live registers spill 80 here)
+                                const bool inside = (int)oaddr >= 0;
+                                f32x4 gm;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) gm[e] = (inside && __builtin_fmaf(yv[e], sc4[e], sh4[e]) > 0.f) ? y[jj][e] : 0.f;
+                                ssum += gm;
+                                ssq += gm * adh_pksub(yv, mean4, m1);
+                                f32x4 v4 = y[jj];
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), orsrc, oaddr,
+                                                                       (8 * th + ii) * o_row + jj * o_px, W_STORE_AUX);
+                                asm volatile("s_nop %1" : "+v"(v4) : "n"(W4_STORE_NOPS) : "memory");
+                                w4_store_mh_round<NT>(acc, m_wbase, jn, thn, 1 + ii * 4 + jj);
+                                continue;
+                            }
+                            f32x4 v4 = y[jj] * sc4 + sh4;
+                            if (d.stats) {
+                                f32x4 vs = v4;
+                                if (ragged) {   // pixels outside the image do not count (a real, workgroup-uniform branch: the asm keeps
+                                    // the compiler from turning it into selects); bit 31 of the store offset marks them
+                                    const bool inside = (int)oaddr >= 0;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) vs[e] = inside ? v4[e] : 0.f;
+                                    asm volatile("" : "+v"(vs));
+                                }
+                                ssum += vs;
+                                ssq += vs * vs;
+                            }
+                            v4 += rres[ii * 4 + jj];      // zeros without a residual
+                            v4 = {fmaxf(v4[0], act_lo), fmaxf(v4[1], act_lo), fmaxf(v4[2], act_lo), fmaxf(v4[3], act_lo)};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), orsrc, oaddr, (8 * th + ii) * o_row + jj * o_px,
+                                                                   W_STORE_AUX);
+                            // gfx950: a 128-bit buffer store whose data VGPRs are overwritten by the very next instructions stores
+                            // the NEW values in some lanes (lanes 12-15 of every 16) even when its soffset is an SGPR (measured:
+                            // tools/dev_w43_probe.py, tools/dev_w32_probe.py; LLVM pads only the immediate-soffset form,
+                            // GCNHazardRecognizer "12-dword store hazard", and schedules such an overwrite right behind the store).
+                            // The asm reads the data registers, so they stay untouched until its wait states have passed.
+                            asm volatile("s_nop %1" : "+v"(v4) : "n"(W4_STORE_NOPS) : "memory");
+                            w4_store_mh_round<NT>(acc, m_wbase, jn, thn, 1 + ii * 4 + jj);
+                        }
+                    }
+                    if (j == 1 && th == 0) W4_STAMP(20);
+                    if (!(j == NT - 1 && th == 1)) {   // the next round's M is complete
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    if (j == 1 && th == 0) W4_STAMP(21);
+                }
+                if (d.stats) {
+                    // sum over the 8 tile rows of this wave (lane bits 3..5; both region halves are already in), then over the 4 waves
+                    // (two tile groups x two output-row halves) through LDS
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int o = 8; o < 64; o <<= 1) {
+                            ssum[e] += __shfl_xor(ssum[e], o, 64);
+                            ssq[e] += __shfl_xor(ssq[e], o, 64);
+                        }
+                    }
+                    if (j) __builtin_amdgcn_s_barrier();   // the previous tile's rows have been read
+                    if (lane < 8) {
+                        *reinterpret_cast<f32x4*>(red + (0 * 4 + wave) * 32 + eq * 4) = ssum;
+                        *reinterpret_cast<f32x4*>(red + (1 * 4 + wave) * 32 + eq * 4) = ssq;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (tid < 64) {
+                        const int which = tid >> 5, cl = tid & 31;
+                        float sv = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sv += red[(which * 4 + r) * 32 + cl];
+                        d.stats[((size_t)region * 2 + which) * d.NcP + co0 + j * 32 + cl] = sv;
+                    }
+                }
             }
         }
+        W4_STAMP(3);
+        if (!has_next) break;
+        // (the last round's M is V, which the next region's first transform writes: behind the barrier at the top of the region)
+        v = vn;
+        region = regn;
+        cg = cgn;
+        tsel ^= 1;
     }
-    W4_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -850,13 +989,31 @@ extern "C" int adh_conv_wino43_num_blocks(const adh_conv_desc* d) {
     return g.nregions;
 }
 
+// Persistent launch: one workgroup per CU (512 registers per lane and ~140 KB of LDS allow no second one anyway), a multiple of
+// 8 so that v & 7 stays the XCD of every virtual block a workgroup runs.
+static int wino43_grid(int nvblocks) {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8)
+            ncu = p.multiProcessorCount / 8 * 8;
+        else
+            ncu = 256;
+        const char* e = getenv("ADH_WINO43_GRID");   // dev: 0 = one workgroup per virtual block (no persistence)
+        if (e && atoi(e) >= 0) ncu = atoi(e) / 8 * 8;
+    }
+    return (ncu && nvblocks > ncu) ? ncu : nvblocks;
+}
+
 template <int NT, bool BNRED = false, bool BF3 = false>
 static int launch_wino43(hipStream_t s, const adh_conv_desc* d, Wino43Geom g) {
     g.ncog = d->NcP / (32 * NT);
-    const int nblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
+    g.nvblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<NT, BNRED, BF3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_wino43_kernel<NT, BNRED, BF3>), dim3(nblocks), dim3(256), BF3 ? W4B_LDS_BYTES : W4_LDS_BYTES, s, *d, g);
+    hipLaunchKernelGGL((conv_wino43_kernel<NT, BNRED, BF3>), dim3(wino43_grid(g.nvblocks)), dim3(256), BF3 ? W4B_LDS_BYTES : W4_LDS_BYTES, s,
+                       *d, g);
     return adh_check_launch();
 }
 

@@ -53,6 +53,7 @@ def main():
         sync.begin_step()
         if step == 0:
             E.RELU_CAPTURE = {}
+            E.CBAM_CAPTURE = {}
         out = model(x)
         loss = l1_loss(out, y)
         loss.backward()
@@ -60,6 +61,11 @@ def main():
             rec["masks"] = {k: (E.RELU_CAPTURE[id(p)] > 0).permute(0, 3, 1, 2).cpu() for k, p in model.named_parameters()
                             if id(p) in E.RELU_CAPTURE}
             E.RELU_CAPTURE = None
+            # ... and the arg-max positions of its attention blocks (the network's other kinks: one flipped arg-max moves the
+            # gradients behind the block by 1e-3 .. 1e-2, tests/_util.py kink_matched.cbam_indices)
+            rec["cbam"] = {k: tuple(t.cpu() for t in E.CBAM_CAPTURE[id(p)]) for k, p in model.named_parameters()
+                           if id(p) in E.CBAM_CAPTURE}
+            E.CBAM_CAPTURE = None
         rec["early"].append(sync._next_bucket)          # buckets already in flight when backward returned
         rec["nbuckets"].append(len(sync.buckets))
         rec["order"].append(list(sync.order))

@@ -71,7 +71,7 @@ def test_two_rank_training_step_matches_shardwise_oracle(tmp_path, backend):
             loss = F.l1_loss(out, clear[2 * r:2 * r + 2])
             loss.backward()
             return loss
-        loss = oracle_with_masks(run, recs[r]["masks"])      # the ReLU masks that rank's kernels used (tests/_util.py)
+        loss = oracle_with_masks(run, recs[r]["masks"], recs[r]["cbam"])      # the ReLU masks / attention arg-max positions that rank's kernels used (tests/_util.py)
         assert abs(float(loss) - recs[r]["loss"]) < 1e-5
         shard_grads.append({k: sd[k].grad for k in recs[0]["grads"]})
         shard_bn.append({k: v.detach() for k, v in sd.items() if "running" in k})
@@ -121,7 +121,7 @@ def test_one_rank_rccl_rehearsal_issues_every_collective(tmp_path, sync_bn):
         loss = F.l1_loss(out, clear)
         loss.backward()
         return loss
-    loss = oracle_with_masks(run, rec["masks"])
+    loss = oracle_with_masks(run, rec["masks"], rec["cbam"])
     assert abs(float(loss) - rec["loss"]) < 1e-5
     for k, g in rec["grads"].items():
         ref = sd[k].grad
@@ -145,7 +145,7 @@ def test_two_rank_sync_bn_matches_the_unsharded_reference(tmp_path, kernels, bac
     images each reproduce the SINGLE-PROCESS reference on the unsharded 4-image batch (/root/reference
     models/dehazing/base_model.py:15-16: BatchNorm2d spans the whole batch there): outputs of both shards (2e-4), BatchNorm
     buffers (1e-5, identical on both ranks), loss, and every synchronized gradient against the float64 oracle of the global
-    L1 loss with the ranks' own ReLU masks replayed (gate: 3 x the fp32 reference's own distance + 3e-4).  Run with the direct
+    L1 loss with the ranks' own ReLU masks and attention arg-max positions replayed (gate: 3 x the fp32 reference's own distance + 3e-4).  Run with the direct
     kernels and with the default Winograd kernels (the replica-BN test above pins ADH_WINOGRAD=0)."""
     world = 2
     recs = _run_ranks(tmp_path, world, 33000, ADH_DDP_SYNC_BN="1", ADH_DDP_BACKEND=backend,
@@ -153,6 +153,8 @@ def test_two_rank_sync_bn_matches_the_unsharded_reference(tmp_path, kernels, bac
     assert all(recs[r]["selfcheck"]["ok"] for r in range(world)), [recs[r]["selfcheck"] for r in range(world)]
     hazy, clear, _ = R.synthetic_batch(2 * world, 32, 48, seed=77)
     masks = {k: torch.cat([recs[r]["masks"][k] for r in range(world)], dim=0) for k in recs[0]["masks"]}
+    # the attention blocks' arg-max positions as the ranks' kernels took them (per image: the shards concatenate)
+    cbam = {k: tuple(torch.cat([recs[r]["cbam"][k][i] for r in range(world)], dim=0) for i in range(2)) for k in recs[0]["cbam"]}
 
     def oracle(dtype):
         sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in recs[0]["sd0"].items()}
@@ -166,7 +168,7 @@ def test_two_rank_sync_bn_matches_the_unsharded_reference(tmp_path, kernels, bac
             loss = F.l1_loss(out, clear.to(dtype))
             loss.backward()
             return out.detach(), loss.detach()
-        out, loss = oracle_with_masks(run, masks)
+        out, loss = oracle_with_masks(run, masks, cbam)
         return out, float(loss), sd
     out32, loss32, sd32 = oracle(torch.float32)
     out64, loss64, sd64 = oracle(torch.float64)
