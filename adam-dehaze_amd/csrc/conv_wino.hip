@@ -531,7 +531,8 @@ extern "C" int adh_conv_wino_forward(void* stream, const adh_conv_desc* d) {
 // raw staging, asm weight prefetch with counted waits); what differs:
 //   * region = 4 x 16 tiles of 3x3 = 12 x 48 virtual pixels, tiles step by 3: the raw halo 13 x 49 pixels is laid out
 //     [row][column mod 3][16 px][16 ch] (+ column 48 of every row in a tail), 40 DMA pieces per slab, 10 per wave; edge
-//     regions load from clamped coordinates (every instruction issues with all lanes) and zero the cells afterwards;
+//     regions load per-lane coordinates (every instruction issues with all lanes), out-of-image cells with an out-of-range
+//     offset for which the LDS-DMA unit writes zeros;
 //   * the raw tile is double buffered and V single buffered (the larger halo does not leave room for two V buffers):
 //     a slab is contracted, then the next one is transformed -- VALU and MFMA work do not overlap anyway;
 //   * the K loop runs over slabs = (16 input channels, input-parity class); a class only changes scalar offsets;
@@ -632,9 +633,12 @@ __device__ __forceinline__ void w3b_stage(const W3Stage& st, const W3Slab& sg, i
             const int rs = (j * 171) >> 9, p = tail ? 0 : j - rs * 3;
             const int r = tail ? (st.px_l < W3_RAW_ROWS ? st.px_l : 0) : rs;
             const int col = tail ? 48 : 3 * st.px_l + p;
-            const int iy = adh_min_i(adh_max_i(sg.iy0 + r * st.xps, 0), st.IH - 1);
-            const int ix = adh_min_i(adh_max_i(sg.ix0 + col * st.xps, 0), st.IW - 1);
-            const int vo = (iy * st.IW + ix) * st.in_cstride * 4 + st.cq_l * 16;
+            // a cell outside the image: bit 31 of the offset = out of range against num_records = 0x7fffffff whatever the scalar
+            // offset, and the LDS-DMA unit writes zeros for such a lane (tools/micro/dma_oob.hip): the padding needs no pass over
+            // the landed halo
+            const int iy = sg.iy0 + r * st.xps, ix = sg.ix0 + col * st.xps;
+            const bool ok = iy >= 0 && iy < st.IH && ix >= 0 && ix < st.IW;
+            const int vo = ok ? (iy * st.IW + ix) * st.in_cstride * 4 + st.cq_l * 16 : (int)0x80000000;
             const int doff = __builtin_amdgcn_readfirstlane(tail ? W3_RAW_ROWS * W3_RAW_PITCH : rs * W3_RAW_PITCH + p * 256);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xr, (lds_void_ptr)(raw + doff), 16, vo, __builtin_amdgcn_readfirstlane(sg.cb), 0, 0);
         }
@@ -796,8 +800,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
                 }
             }
         } else {
-            // clamped per-lane coordinates: every instruction issues with all lanes; fix_raw zeroes the cells that lie
-            // outside the image after they have landed
+            // per-lane coordinates: every instruction issues with all lanes; a cell outside the image gets an out-of-range
+            // offset (bit 31), for which the LDS-DMA unit writes zeros
 #pragma unroll
             for (int u = u0; u < u1; ++u) {
                 const int j = 4 * u + wv;
@@ -805,42 +809,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
                 const int rs = (j * 171) >> 9, p = tail ? 0 : j - rs * 3;      // full pieces: row, plane (wave-uniform)
                 const int r = tail ? (px_l < W3_RAW_ROWS ? px_l : 0) : rs;
                 const int col = tail ? 48 : 3 * px_l + p;
-                const int iy = adh_min_i(adh_max_i(iy0 + r * g.xps, 0), d.IH - 1);
-                const int ix = adh_min_i(adh_max_i(ix0 + col * g.xps, 0), d.IW - 1);
-                const int vo = (iy * d.IW + ix) * d.in_cstride * 4 + cq_l * 16;
+                const int iy = iy0 + r * g.xps, ix = ix0 + col * g.xps;
+                const bool ok = iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
+                const int vo = ok ? (iy * d.IW + ix) * d.in_cstride * 4 + cq_l * 16 : (int)0x80000000;
                 const int doff = __builtin_amdgcn_readfirstlane(tail ? W3_RAW_ROWS * W3_RAW_PITCH : rs * W3_RAW_PITCH + p * 256);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + doff), 16, vo, __builtin_amdgcn_readfirstlane(cb), 0, 0);
             }
         }
     };
-    auto fix_raw = [&](int slab, int buf) {
-        const int chunk = slab / g.ncls, c = slab - chunk * g.ncls;
-        const int iy0 = vy0 * g.xps + g.ymin[c + mc], ix0 = vx0 * g.xps + g.xmin[c + mc];
-        if (iy0 >= 0 && iy0 + 12 * g.xps < d.IH && ix0 >= 0 && ix0 + 48 * g.xps < d.IW) return;
-        float* raw = rawbase + buf * W3_RAW_F;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        // bf16 x 3 form: the per-lane geometry is rebuilt from v_mbcnt here -- hoisted out of the slab loop (as hipcc does with
-        // lane-derived values) it would sit in registers the contraction has no room for, i.e. in scratch
-        int ln = lane;
-        if constexpr (BF3) {
-            ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            asm volatile("" : "+v"(ln));
-        }
-        const int pxl = ln >> 2;
-#pragma unroll
-        for (int u = 0; u < 10; ++u) {
-            const int j = 4 * u + wave;
-            const bool tail = j >= 39;
-            const int r = tail ? pxl : ((j * 171) >> 9);
-            const int p = tail ? 0 : j - ((j * 171) >> 9) * 3;
-            const int col = tail ? 48 : 3 * pxl + p;
-            const int iy = iy0 + r * g.xps, ix = ix0 + col * g.xps;
-            const bool ok = iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
-            float* dst = (tail ? raw + W3_RAW_ROWS * W3_RAW_PITCH : raw + r * W3_RAW_PITCH + p * 256) + ln * 4;
-            if (!ok && (!tail || pxl < W3_RAW_ROWS)) *reinterpret_cast<f32x4*>(dst) = z;
-        }
-    };
-
     // ------------------------------------------------------------------ input transform: thread = (tile, channel quad)
     const int tcol = lane >> 2;          // tile row = wave
     const int tile_t = wave * 16 + tcol;
@@ -922,8 +898,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     if constexpr (!BF3) w2_load_b<NT>(bv[0], b_voff, b_ptr(0, 0, 0));
     stage_raw(slab_geom(0), 0, 0, 10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fix_raw(0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (!(W3_DBG & 1)) transform(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1014,7 +988,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
         }
         // ---- V is free once every wave is here; raw(s+1) landed during this slab (last wait above)
         if (s == 1) W3_STAMP(9);
-        fix_raw(sn, (s + 1) & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (s == 1) W3_STAMP(10);

@@ -610,6 +610,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     // ------------------------------------------------------------------ prologue of the workgroup: table and first chunk of its first region
     int cg, region = region_of(v, cg);
     if (region >= g.nregions) return;
+    // (Persistent workgroups start together and do identical work, so all CUs stage, transform and contract in phase.  A one-off
+    // start-up delay of 1 .. 14 us by workgroup index made no difference in either form: measured, removed.)
     {
         int rr = region;
         const int tx = rr % g.tiles_x;
@@ -678,9 +680,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         }
         W4_STAMP(5);
 #pragma unroll
-        for (int t = 0; t < 9 * NT; ++t)   // (~0.9 us per region.  Tried: the first chunk's first MFMA on every tile with C = 0 instead -- a second
-#pragma unroll                             // instantiation of the contraction behind `if (c == 0)`: hipcc then spills ~700 registers.)
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < 9 * NT; ++t)   // (~0.9 us per region.  Tried: (i) the first chunk's first MFMA on every tile with C = 0 instead -- a second
+#pragma unroll                             // instantiation of the contraction behind `if (c == 0)`: hipcc spills ~700 registers; (ii) one
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;   // v_mfma_f32_32x32x16_bf16 with zero operands per tile: no measurable change.)
         // first region: its halo was requested above; later regions: it landed during the previous region's last contraction and
         // was waited for (vmcnt(0)) in front of that region's epilogue barriers
         if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
