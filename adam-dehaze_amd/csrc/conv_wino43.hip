@@ -49,10 +49,10 @@
 #define W4_SLOTS 612                               // pixel slots of the raw halo: 18 rows x 34 columns
 #define W4_ROWSLOTS 34
 #define W4_RAWF (40 * 256)                         // floats of the raw buffer: 40 DMA pieces of 16 slots (640 >= 612 slots)
-#define W4_TAB (W4_VF + W4_RAWF)                   // float offset of the two lane offset tables [2][640 slots][4 quads] (this region's / the next one's)
+#define W4_TAB (W4_VF + W4_RAWF)                   // float offset of the lane offset tables [3][640 slots][4 quads]: relative | absolute x 2
 #define W4_TABF (4 * 640)                          // floats of one table
 #define W4_MF (36 * 16 * 32)                       // floats of the epilogue's M: 36 frequencies x 16 tiles x 32 co = exactly V (73,728 B)
-#define W4_RED (W4_TAB + 2 * W4_TABF)              // statistics scratch (behind the tables)
+#define W4_RED (W4_TAB + 3 * W4_TABF)              // statistics scratch (behind the tables)
 #define W4_LDS_BYTES ((W4_RED + 2 * 8 * 32) * 4)
 static_assert(W4_MF <= W4_VF, "the epilogue's M must not reach the raw halo: the next region's first chunk lands there meanwhile");
 #ifndef W4_P2
@@ -75,9 +75,8 @@ static_assert(W4_MF <= W4_VF, "the epilogue's M must not reach the raw halo: the
 // one entry per slot (the channel quad is added per lane).
 #define W4B_RAW_B 73728
 #define W4B_RAWBUF_B 40960
-#define W4B_TAB_B 155648                           // two tables of 640 offsets (this region's / the next one's)
-#define W4B_RED_B (W4B_TAB_B + 2 * 2560)
-#define W4B_LDS_BYTES (W4B_RED_B + 2048)
+#define W4B_TAB_B 155648                           // three tables of 640 offsets: relative | absolute x 2
+#define W4B_LDS_BYTES (W4B_TAB_B + 3 * 2560)       // (the statistics scratch sits in the raw buffer the last chunk has consumed)
 static_assert(W4B_LDS_BYTES <= 160 * 1024, "LDS map of the bf16 x 3 variant");
 #define B3_NO_SPLIT ((W4_DBG & 16) != 0)
 #include "bf16x3.h"
@@ -101,6 +100,7 @@ struct Wino43Geom {
     int KQtot;
     int ncog;
     int nvblocks;                // virtual blocks = 8-aligned regions x output-channel groups, dealt to the persistent workgroups
+    unsigned m_ncog, m_tx, m_ty; // ceil(2^32 / divisor) of ncog, tiles_x, tiles_y (0: divide): n / d = mulhi(n, m) for n d < 2^32
     const float* bn_mean;        // BNRED launches: the producing layer's batch mean (centres the second sum)
 };
 
@@ -128,6 +128,23 @@ __device__ __forceinline__ void w4_mfma(f32x16& c, float a, float b) {
     }
 }
 // one group: local frequency FI, NT output-channel tiles, k-steps KK .. KEND-1 (a whole group: 0 .. 3)
+#ifndef W4_MFMA_ZERO
+#define W4_MFMA_ZERO 1   // 1: accumulators zeroed by one v_mfma_f32_32x32x16_bf16 with zero operands and C = 0 per tile (16 registers in 32 cycles
+#endif                   // of the matrix pipe) instead of 16 v_mov / v_accvgpr_write each
+template <int NT, int T = 0>
+__device__ __forceinline__ void w4_acc_zero_(f32x16 (&acc)[9 * NT], const u32x4& z) {
+    if constexpr (T < 9 * NT) {
+        if constexpr (w4_in_agpr<NT, T / NT, T % NT>()) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[T]) : "v"(z));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=&v"(acc[T]) : "v"(z));
+        w4_acc_zero_<NT, T + 1>(acc, z);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void w4_acc_zero(f32x16 (&acc)[9 * NT]) {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    asm volatile("s_nop 1" : "+v"(z));   // (an MFMA reads its operands two wait states after a VALU write at the earliest: common.h)
+    w4_acc_zero_<NT>(acc, z);
+}
 // (Z: this group is the first one on its accumulator tiles in the region: k-step 0 starts them from zero)
 template <int NT, int FI, int KK, int J, int KEND = 4, bool Z = false>
 __device__ __forceinline__ void w4_group(f32x16 (&acc)[9 * NT], const f32x4& a, const f32x4 (&b)[NT]) {
@@ -424,6 +441,10 @@ __device__ __forceinline__ void w4b_bt_store_staging(f32x4 (&d)[6], float* dst, 
     put(4, n.b * s + r);
 }
 
+// where a region sits: image, output origin, byte offset of the halo's first pixel (0 for a border region), halo not inside the image
+// (namespace scope: a local type inside the __global__ template costs the kernel its host stub in hipcc)
+struct W4Where { int n, oy0, ox0, base; bool border; };
+
 template <int NT, bool BNRED = false, bool BF3 = false>
 __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc d, const Wino43Geom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // V | raw | two slot tables | red ; the epilogue's M aliases V only
@@ -432,11 +453,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     // form: one entry per slot (the lane adds its quad) and two raw buffers.  A slot outside the image (and the padding slots >= 612)
     // has BIT 31 of its offset set: out of range against num_records = 0x7fffffff for every scalar offset, and the LDS-DMA unit
     // writes ZEROS for an out-of-range lane (tools/micro/dma_oob.hip) -- the padding of the convolution costs no flags and no pass
-    // over the landed halo.  Two tables: the persistent workgroup stages the first chunk of its NEXT region during the last
-    // contraction of the current one, from that region's table.
+    // over the landed halo.  Table 0 holds offsets RELATIVE to the halo's first pixel and serves every region whose halo lies inside
+    // the image (the region's origin goes into the scalar offset of the pieces): built once per workgroup.  A border region gets an
+    // absolute table (clamped coordinates, bit 31) in table 1 or 2 -- two, because the persistent workgroup stages the first chunk
+    // of its NEXT region during the last contraction of the current one.
     constexpr int TABN = BF3 ? 640 : W4_TABF;                            // ints per table
     int* const tab_base = reinterpret_cast<int*>(lds + (BF3 ? W4B_TAB_B / 4 : W4_TAB));
-    float* const red = lds + (BF3 ? W4B_RED_B / 4 : W4_RED);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -447,21 +469,39 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     // ------------------------------------------------------------------ persistent workgroup: virtual block ids v = blockIdx.x + k gridDim.x
     // (gridDim.x is a multiple of 8: v & 7 = the XCD, as for a plain launch).  v -> (output-channel group, region) as before.
     int v = blockIdx.x;
+    // n / dv for a workgroup-uniform n: one s_mul_hi_u32 with the host's reciprocal (the decode of a region is six divisions by
+    // launch constants; as runtime divisions they were a third of the 1.8 us a persistent workgroup spent between two regions)
+    // (readfirstlane: the multiply is a VALU instruction, and a scalar offset or resource derived from a VGPR turns every LDS-DMA
+    // piece into a waterfall loop)
+    auto udiv = [&](int n, int dv, unsigned m) { return __builtin_amdgcn_readfirstlane(m ? (int)__umulhi((unsigned)n, m) : n / dv); };
     auto region_of = [&](int vb, int& cgo) {
-        const int q = vb >> 3;
-        cgo = q % g.ncog;
-        return (q / g.ncog) * 8 + (vb & 7);
+        const int q = vb >> 3, qd = udiv(q, g.ncog, g.m_ncog);
+        cgo = q - qd * g.ncog;
+        return qd * 8 + (vb & 7);
     };
+    typedef W4Where Where;
     const int xcs = d.in_cstride * 4;
-    auto build_table = [&](int* tab, int oy0, int ox0) {   // slot s = row*34 + {9,9,8,8 per plane}
+    auto where_of = [&](int reg) {
+        Where w;
+        const int r1 = udiv(reg, g.tiles_x, g.m_tx), tx = reg - r1 * g.tiles_x;
+        w.n = udiv(r1, g.tiles_y, g.m_ty);
+        const int ty = r1 - w.n * g.tiles_y;
+        w.oy0 = ty * 16;
+        w.ox0 = tx * 32;
+        w.border = !(w.oy0 >= 1 && w.oy0 + 17 <= d.IH && w.ox0 >= 1 && w.ox0 + 33 <= d.IW);
+        w.base = w.border ? 0 : ((w.oy0 - 1) * d.IW + w.ox0 - 1) * xcs;
+        return w;
+    };
+    // slot s = row*34 + {9,9,8,8 per plane}.  REL: offsets relative to the halo's first pixel, no clamping
+    auto build_table = [&](int* tab, int oy0, int ox0, bool rel) {
         for (int s = tid; s < 640; s += 256) {
             const int sc = s < W4_SLOTS ? s : W4_SLOTS - 1;
             const int row = sc / W4_ROWSLOTS, rem = sc - row * W4_ROWSLOTS;
             const int plane = rem < 9 ? 0 : (rem < 18 ? 1 : (rem < 26 ? 2 : 3));
             const int idx = rem - (plane == 0 ? 0 : (plane == 1 ? 9 : (plane == 2 ? 18 : 26)));
-            const int iy = oy0 - 1 + row, ix = ox0 - 1 + 4 * idx + plane;
-            const int iyc = adh_min_i(adh_max_i(iy, 0), d.IH - 1), ixc = adh_min_i(adh_max_i(ix, 0), d.IW - 1);
-            const bool ok = s < W4_SLOTS && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
+            const int iy = rel ? row : oy0 - 1 + row, ix = rel ? 4 * idx + plane : ox0 - 1 + 4 * idx + plane;
+            const int iyc = rel ? iy : adh_min_i(adh_max_i(iy, 0), d.IH - 1), ixc = rel ? ix : adh_min_i(adh_max_i(ix, 0), d.IW - 1);
+            const bool ok = s < W4_SLOTS && (rel || (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW));
             const int off = ((iyc * d.IW + ixc) * xcs) | (ok ? 0 : (int)0x80000000);
             typedef int i32x4 __attribute__((ext_vector_type(4)));
             if constexpr (BF3) tab[s] = off;
@@ -612,29 +652,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
     if (region >= g.nregions) return;
     // (Persistent workgroups start together and do identical work, so all CUs stage, transform and contract in phase.  A one-off
     // start-up delay of 1 .. 14 us by workgroup index made no difference in either form: measured, removed.)
-    {
-        int rr = region;
-        const int tx = rr % g.tiles_x;
-        rr /= g.tiles_x;
-        const int ty = rr % g.tiles_y;
-        const int n = rr / g.tiles_y;
-        build_table(tab_base, ty * 16, tx * 32);
-        st.rsrc = image_rsrc(image_ptr(n));
-    }
+    Where wc = where_of(region);
+    build_table(tab_base, 0, 0, true);
+    if (wc.border) build_table(tab_base + TABN, wc.oy0, wc.ox0, false);
+    st.rsrc = image_rsrc(image_ptr(wc.n));
     W4_STAMP(0);
-    __syncthreads();   // slot table
+    __syncthreads();   // slot tables
     {   // chunk 0 of the first region; the later chunks (and regions) arrive piece by piece inside the main loop
+        const int* const tab0 = tab_base + (wc.border ? TABN : 0);
         int vo[10];   // all table reads first: one LDS round trip instead of ten
 #pragma unroll
-        for (int u = 0; u < 10; ++u) vo[u] = tab_base[tab_lane_o + TABU * u] + (BF3 ? quad16_o : 0);
+        for (int u = 0; u < 10; ++u) vo[u] = tab0[tab_lane_o + TABU * u] + (BF3 ? quad16_o : 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 10; ++u)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_ptr4)(reinterpret_cast<char*>(lds) + st.lds_wave + u * 4096), 16,
-                                                     vo[u], 0, 0, 0);
+                                                     vo[u], wc.base, 0, 0);
     }
     int cpar = 0;      // bf16 x 3 form: the raw buffer the next transform reads (toggles per chunk, across regions)
-    int tsel = 0;      // which table is this region's
+    int tsel = 0;      // which absolute table is this region's (if it is a border region)
 
 #pragma unroll 1
     for (int it = 0;; ++it) {
@@ -645,16 +681,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             w4_prof_buf[v * 32 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
         }
 #endif
-        int rr = region;
-        const int tx = rr % g.tiles_x;
-        rr /= g.tiles_x;
-        const int ty = rr % g.tiles_y;
-        const int n = rr / g.tiles_y;
-        const int oy0 = ty * 16, ox0 = tx * 32;
+        const int n = wc.n, oy0 = wc.oy0, ox0 = wc.ox0;
         const int co0 = cg * 32 * NT;
         const float* const in_cur = image_ptr(n);
-        int* const tab_cur = tab_base + tsel * TABN;
-        int* const tab_nxt = tab_base + (tsel ^ 1) * TABN;
+        int* const tab_cur = wc.border ? tab_base + (1 + tsel) * TABN : tab_base;
         // the next region of this workgroup (regions grow with v: the first invalid one ends the list)
         const int vn = v + (int)gridDim.x;
         int cgn = 0, regn = 0;
@@ -663,13 +693,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             regn = region_of(vn, cgn);
             has_next = regn < g.nregions;
         }
+        Where wn = wc;
         const float* in_next = in_cur;
-        if (has_next) {   // its table (the buffer's last reader was the previous region's main loop) and image
-            int r2 = regn;
-            const int tx2 = r2 % g.tiles_x;
-            r2 /= g.tiles_x;
-            build_table(tab_nxt, (r2 % g.tiles_y) * 16, tx2 * 32);
-            in_next = image_ptr(r2 / g.tiles_y);
+        int* tab_nxt = tab_cur;
+        if (has_next) {   // its image and, for a border region, its table (that buffer's last reader was the previous region's main loop)
+            wn = where_of(regn);
+            in_next = image_ptr(wn.n);
+            tab_nxt = tab_base;
+            if (wn.border) {
+                tab_nxt = tab_base + (1 + (tsel ^ 1)) * TABN;
+                build_table(tab_nxt, wn.oy0, wn.ox0, false);
+            }
         }
         W4_STAMP(4);
         const float* const b_wave = d.wp + ((int64_t)(wave * 9) * g.KQtot * d.NcP + co0) * 4;
@@ -679,10 +713,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             w4_load_b<NT>(bv[1], b_voff, b_wave + b_fstride);
         }
         W4_STAMP(5);
+#if W4_MFMA_ZERO
+        w4_acc_zero<NT>(acc);
+#else
 #pragma unroll
-        for (int t = 0; t < 9 * NT; ++t)   // (~0.9 us per region.  Tried: (i) the first chunk's first MFMA on every tile with C = 0 instead -- a second
-#pragma unroll                             // instantiation of the contraction behind `if (c == 0)`: hipcc spills ~700 registers; (ii) one
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;   // v_mfma_f32_32x32x16_bf16 with zero operands per tile: no measurable change.)
+        for (int t = 0; t < 9 * NT; ++t)   // (~0.9 us per region.  Tried: the first chunk's first MFMA on every tile with C = 0 instead -- a second
+#pragma unroll                             // instantiation of the contraction behind `if (c == 0)`: hipcc spills ~700 registers.)
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#endif
         // first region: its halo was requested above; later regions: it landed during the previous region's last contraction and
         // was waited for (vmcnt(0)) in front of that region's epilogue barriers
         if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -696,7 +734,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             // what this chunk stages: the next chunk of this region, or -- last chunk -- the first chunk of the next region (from its
             // table and image); the very last chunk of the workgroup re-stages itself (uniform counts)
             const bool cross = !more && has_next;
-            st.cb = more ? (c + 1) * (W4_KC * 4) : (cross ? 0 : c * (W4_KC * 4));
+            st.cb = __builtin_amdgcn_readfirstlane((more ? (c + 1) * (W4_KC * 4) : (cross ? 0 : c * (W4_KC * 4))) + (cross ? wn.base : wc.base));
             st.rsrc = image_rsrc(cross ? in_next : in_cur);
             const int* const stab = cross ? tab_nxt : tab_cur;
             st.tab_lane = stab + tab_lane_o;
@@ -790,6 +828,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
             const unsigned m_wbase = (unsigned)((wave * 9) * 2048 + h * 128 + l31 * 4);   // byte address of M[9 wave][h][l31]
             const float* const mp = M + etp * 32 + eq * 4;
             const float m1 = adh_opaque(-1.f);
+            // statistics scratch: behind the tables; bf16 x 3 form (no room left): in the raw buffer the last chunk has consumed
+            // (cpar is the one the next region's first chunk has landed in)
+            float* const red = BF3 ? lds + RAW0 + (cpar ^ 1) * (W4B_RAWBUF_B / 4) : lds + W4_RED;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             // (V fully consumed: barrier at the end of the last chunk)
             w4_store_mh<NT, 0>(acc, m_wbase, 0);
@@ -951,6 +992,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43_kernel(const adh_conv_desc
         v = vn;
         region = regn;
         cg = cgn;
+        wc = wn;
         tsel ^= 1;
     }
 }
@@ -1012,6 +1054,14 @@ template <int NT, bool BNRED = false, bool BF3 = false>
 static int launch_wino43(hipStream_t s, const adh_conv_desc* d, Wino43Geom g) {
     g.ncog = d->NcP / (32 * NT);
     g.nvblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
+    // reciprocals for the region decode: n / d == mulhi(n, ceil(2^32 / d)) whenever n d < 2^32 (n <= nvblocks here); d = 1 and
+    // oversized problems divide
+    auto recip = [&](int dv) {
+        return (dv > 1 && (int64_t)g.nvblocks * dv < (1ll << 32)) ? (unsigned)(((1ull << 32) + (unsigned)dv - 1) / (unsigned)dv) : 0u;
+    };
+    g.m_ncog = recip(g.ncog);
+    g.m_tx = recip(g.tiles_x);
+    g.m_ty = recip(g.tiles_y);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<NT, BNRED, BF3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((conv_wino43_kernel<NT, BNRED, BF3>), dim3(wino43_grid(g.nvblocks)), dim3(256), BF3 ? W4B_LDS_BYTES : W4_LDS_BYTES, s,

@@ -77,6 +77,10 @@ def main():
     for name, a, c in (("prologue", 0, 1), ("main loop", 1, 2), ("epilogue", 2, 3), ("total", 0, 3)):
         dt = (t[:, c] - t[:, a]) * tick_us
         print(f"  {name:10s} mean {dt.mean():7.2f} us  p10 {np.percentile(dt, 10):7.2f}  p50 {np.percentile(dt, 50):7.2f}  p90 {np.percentile(dt, 90):7.2f}")
+    if args.kernel == "w43" and (b[:, 4] != 0).all() and (b[:, 5] != 0).all():   # persistent form: the top of a region
+        for name, a, c in (("region top: next table", 0, 4), ("first weights", 4, 5), ("zero + barrier", 5, 1)):
+            dt = (b[:, c].astype(np.float64) - b[:, a].astype(np.float64)) * tick_us
+            print(f"  {name:22s} mean {dt.mean():7.2f} us  p10 {np.percentile(dt, 10):7.2f}  p50 {np.percentile(dt, 50):7.2f}  p90 {np.percentile(dt, 90):7.2f}")
     chunk_rows = (("chunk 1: stage issue", 0, 1), ("transform", 1, 2), ("barrier", 2, 3), ("contraction", 3, 4), ("fix + barrier", 4, 5), ("whole chunk", 0, 5))
     if args.kernel == "w32":   # (a convT launch runs one class per launch: the event time covers the four launches, the stamps the last)
         chunk_rows = (("slab 1: contraction", 0, 1), ("fix + barrier", 1, 2), ("transform", 2, 3), ("barrier", 3, 4), ("whole slab", 0, 4))
