@@ -153,7 +153,7 @@ def pmc_traffic(family):
     (tools/pmc_bench.sh -> profiles/r0N_pmc_bench.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for
     gfx950).  None when the file is absent."""
     ks, src = None, None
-    for name in ("r04_pmc_bench.json", "r03_pmc_bench.json", "r02_pmc_bench.json", "r01_pmc_bench.json"):     # the newest committed pass wins
+    for name in ("r04b_pmc_bench.json", "r04_pmc_bench.json", "r03_pmc_bench.json", "r02_pmc_bench.json", "r01_pmc_bench.json"):     # the newest committed pass wins
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as f:
