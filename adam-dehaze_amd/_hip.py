@@ -82,6 +82,7 @@ _SIGNATURES = {
     "adh_conv_wino43_forward": [vp, PD],
     "adh_conv_wino43_dgrad_bnred": [vp, PD, vp],
     "adh_pack_weights_wino43": [vp, vp, PL, vp],
+    "adh_conv_wino43_set_persistent": [i32],
     "adh_conv_wino43_forward_bf16x3": [vp, PD],
     "adh_conv_wino43_dgrad_bnred_bf16x3": [vp, PD, vp],
     "adh_pack_weights_wino43_bf16x3": [vp, vp, PL, vp],
@@ -201,7 +202,7 @@ _SIGNATURES = {
 }
 
 # functions that return a count / size rather than a status code
-_VALUE_FUNCS = {"adh_version", "adh_conv_fewout_supported", "adh_conv_fewin_supported", "adh_conv_fewin_num_blocks", "adh_conv_wgrad_wino32_launches", "adh_conv_wino_supported", "adh_conv_wino_num_blocks", "adh_conv_wino32_supported", "adh_conv_wino43_supported", "adh_conv_wino43_num_blocks",
+_VALUE_FUNCS = {"adh_version", "adh_conv_fewout_supported", "adh_conv_fewin_supported", "adh_conv_fewin_num_blocks", "adh_conv_wgrad_wino32_launches", "adh_conv_wino_supported", "adh_conv_wino_num_blocks", "adh_conv_wino32_supported", "adh_conv_wino43_supported", "adh_conv_wino43_num_blocks", "adh_conv_wino43_set_persistent",
                 "adh_conv_wino32_num_blocks", "adh_conv_wgrad_wino_groups", "adh_conv_wgrad_wino32_groups", "adh_conv_wgrad_wino32_classes", "adh_conv_wgrad_wino32_tiles", "adh_conv_wgrad_wino43_groups", "adh_conv_wgrad_wino43_strips", "adh_conv_wgrad_small_slabs", "adh_conv_wgrad_stem_slabs", "adh_conv_stem_num_blocks", "adh_conv_wgrad_slabs", "adh_conv_wgrad_groups", "adh_conv_lds_bytes", "adh_conv_num_blocks", "adh_bn_bwd_num_blocks",
                 "adh_cbam_pool_num_blocks", "adh_cbam_bwd_b_num_blocks", "adh_head_blend_bwd_num_blocks",
                 "adh_reduce_num_blocks", "adh_lpips_layer_num_blocks", "adh_adam_chunk_elems", "adh_nms_words", "adh_augment_num_blocks", "adh_psnr_num_blocks", "adh_cbam_bwd_d_scratch_floats",

@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const adh_conv_desc d
     // 32 pieces per chunk, 8 per wave (piece j = 4u + wave): j < 20 full pieces (row j/2, column parity j&1, 16 pixels x
     // 16 ch), 20 <= j < 30 the tail of row j-20 (columns 32, 33 in lanes 0-7; lanes 8-15 re-read column 0 into the
     // pad so the instruction always issues), j >= 30 repeat pieces 28, 29: every wave issues exactly 8 per chunk,
-    // which is what the hand-counted vmcnt waits below rely on.  Out-of-image rows are fetched from the clamped row
-    // and zeroed after they land; out-of-image columns are lane-masked and zeroed.
+    // which is what the hand-counted vmcnt waits below rely on.  Out-of-image cells are fetched with an out-of-range offset: the LDS-DMA
+    // unit writes zeros for them.
     const int xcs = d.in_cstride * 4;                                    // pixel pitch in bytes
     const float* xbase = d.in + (int64_t)n * d.IH * d.IW * d.in_cstride - d.in_cstride;   // pixel (0, -1) of image n
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, 0x7fffffff, 0x00020000);
@@ -188,27 +188,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const adh_conv_desc d
                 }
             }
         } else {
+            // edge regions: a cell outside the image gets an out-of-range offset (bit 31 against num_records = 0x7fffffff), for which
+            // the LDS-DMA unit writes zeros (tools/micro/dma_oob.hip): the padding needs no pass over the landed tile.  (Lanes 16 .. 63
+            // of a tail piece stay masked: their 16 bytes would land in the next row.)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bool ok = p_tail[u] ? ok_t : (p_par[u] ? ok_f1 : ok_f0);
-                const int vo = p_tail[u] ? vtail : vfull;
-                if (ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + p_dst[u]), 16, vo, p_so[u] + cb, 0, 0);
+                const bool ok = p_rowok[u] && (p_tail[u] ? (lane >= 8 || ok_t) : (p_par[u] ? ok_f1 : ok_f0));
+                const int vo = ok ? (p_tail[u] ? vtail : vfull) : (int)0x80000000;
+                if (!p_tail[u] || lane < 16)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(raw + p_dst[u]), 16, vo, p_so[u] + cb, 0, 0);
             }
         }
     };
-    // zero what the padding semantics require (edge regions only; runs after this wave's pieces have landed)
-    auto fix_raw = [&]() {
-        if (interior) return;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            float* dst = raw + p_dst[u] + lane * 4;
-            const bool ok = p_tail[u] ? ok_t : (p_par[u] ? ok_f1 : ok_f0);
-            const bool mine = p_tail[u] ? lane < 8 : true;
-            if (mine && !(p_rowok[u] && ok)) *reinterpret_cast<f32x4*>(dst) = z;
-        }
-    };
-
     // ------------------------------------------------------------------ input transform: thread = (tile, channel quad)
     const int tcol = lane >> 2;          // tile row = wave
     const int tile_t = wave * 16 + tcol;
@@ -271,8 +262,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const adh_conv_desc d
     w2_load_b<NT>(bv[0], b_voff, b_ptr(0, 0, 0));
     stage_raw(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fix_raw();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     transform(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -306,7 +295,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const adh_conv_desc d
         w2_wait_b<NT, NT>(bv[1]);
         w2_group<NT, 3, 0, 0, 0>(acc, av[1], bv[1]);
         // ---- raw(c+1) complete -> transform into the other V buffer
-        fix_raw();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // (unconditional: after the last chunk it fills the idle V buffer from the re-staged tile -- a branch here

@@ -1034,8 +1034,22 @@ extern "C" int adh_conv_wino43_num_blocks(const adh_conv_desc* d) {
 }
 
 // Persistent launch: one workgroup per CU (512 registers per lane and ~140 KB of LDS allow no second one anyway), a multiple of
-// 8 so that v & 7 stays the XCD of every virtual block a workgroup runs.
+// 8 so that v & 7 stays the XCD of every virtual block a workgroup runs.  The shares are STATIC (workgroup w runs blocks w, w + G, ..):
+// right when the launch has the chip to itself, wrong when another stream's kernel holds CUs for long -- a workgroup that starts
+// late still owns 1 / G of the work and the whole launch waits for it.  The data-parallel step overlaps its gradient all-reduces
+// with the backward pass, so parallel.GradientSynchronizer switches to one workgroup per virtual block
+// (adh_conv_wino43_set_persistent(0)); so does ADH_WINO43_GRID=0.  (A dynamic hand-out -- per-XCD atomic counters, the block after
+// next requested at the top of the epilogue -- was built and measured: hipcc's atomicAdd waits for its result on the spot, ~0.7 us
+// per region = +1 % at 96 channels; an asm atomic left in flight across the epilogue is exactly the register-copy hazard of
+// DESIGN 4.15.  Not adopted.)
+static int w4_persistent = 1;
+extern "C" int adh_conv_wino43_set_persistent(int on) {
+    const int old = w4_persistent;
+    w4_persistent = on ? 1 : 0;
+    return old;
+}
 static int wino43_grid(int nvblocks) {
+    if (!w4_persistent) return nvblocks;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;

@@ -128,6 +128,11 @@ class GradientSynchronizer:
         E.GRAD_SINK, E.GRAD_READY = self._sink, self._on_ready
         if self.sync_bn and not self.solo:
             E.SYNC_BN = self._sync_bn_all_reduce
+        if not self.solo and torch.cuda.is_available():
+            # bucket all-reduces run on the backend's stream beside the backward pass: their kernels hold CUs, and a persistent
+            # F(4x4,3x3) launch (a static share of the regions per workgroup) would wait for the workgroups that start late
+            from . import _hip as H
+            self._wino43_persistent = H.value("adh_conv_wino43_set_persistent", 0)
         self._installed = True
 
     def uninstall(self):
@@ -135,6 +140,10 @@ class GradientSynchronizer:
         if self._installed and E.GRAD_READY == self._on_ready:
             E.GRAD_SINK = E.GRAD_READY = None
             E.SYNC_BN = None
+        if getattr(self, "_wino43_persistent", None) is not None:
+            from . import _hip as H
+            H.value("adh_conv_wino43_set_persistent", self._wino43_persistent)
+            self._wino43_persistent = None
         self._installed = False
 
     @staticmethod

@@ -140,6 +140,12 @@ int adh_conv_wino43_forward(void* stream, const adh_conv_desc* d);
  * ResidualBlock (/root/reference models/dehazing/base_model.py:4-24,26-41). */
 int adh_conv_wino43_dgrad_bnred(void* stream, const adh_conv_desc* d, const float* bn_mean);
 int adh_pack_weights_wino43(void* stream, const float* src, const adh_wlayout* L, float* wp);
+/* Launch shape of the F(4x4,3x3) kernels (library-wide; returns the previous setting).  1 (default): persistent -- one workgroup per
+ * CU walks a static share of the regions and stages the next region's first chunk during the current one's last contraction
+ * (DESIGN 4.17).  0: one workgroup per region, for processes whose other streams hold CUs while these kernels run (the
+ * data-parallel step: gradient all-reduces beside the backward pass) -- a static share would make the launch wait for the
+ * workgroups that start late.  No counterpart in the reference (ATen picks its own launch shapes). */
+int adh_conv_wino43_set_persistent(int on);
 /* Opt-in (round 4; host switch ADH_CONTRACT=bf16x3, the default stays the fp32 MFMA): the same two launches with the contraction
  * on v_mfma_f32_32x32x16_bf16.  Both operands are split EXACTLY into three bf16 planes (x = hi + mid + lo, 3 x 8 significant
  * bits; the transformed input inside the kernel, U at pack time) and the six significant cross terms are accumulated in fp32:
