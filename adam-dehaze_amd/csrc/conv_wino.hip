@@ -702,6 +702,7 @@ struct Wino32Geom {
     // merged launch (adh_conv_wino32_forward_multi): `nmerge` single-class descriptors that differ only in their weights, output
     // parity offset, halo origin (ymin / xmin [m]) and statistics rows run as ONE grid of nmerge * mblocks workgroups, region-major
     int nmerge, mblocks;
+    int region0;                 // first region of this launch (a layer may be split into a main and a tail launch, wino32_tail_split)
     int m_out_oy[4], m_out_ox[4];
     const float* m_wp[4];
     float* m_stats[4];
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino32_kernel(const adh_conv_desc
     }
 #endif
     const int cg = rem - mc * g.ncog;
-    const int region = r8 * 8 + (bid & 7);
+    const int region = g.region0 + r8 * 8 + (bid & 7);
     if (region >= g.nregions) return;
     int rr = region;
     const int tx = rr % g.tiles_x;
@@ -1161,6 +1162,7 @@ static int wino32_plan(const adh_conv_desc* d, Wino32Geom* g) {
     g->KQtot = d->Cin / 4;
     g->wcls = 16 * g->KQtot * d->NcP * 4;
     g->nmerge = 1;
+    g->region0 = 0;
     g->mblocks = 0;
     return 1;
 }
@@ -1176,14 +1178,51 @@ extern "C" int adh_conv_wino32_num_blocks(const adh_conv_desc* d) {
     return g.nregions;
 }
 
+// Grid tails.  A launch of B blocks runs ceil(B / CUs) rounds of one workgroup per CU; Conv2d k4 s2 96 -> 192 at the headline size is
+// 3,872 blocks = 15.125 rounds: the last round keeps 32 of 256 CUs busy for a full region time (5.5 % of the launch; 8.25 rounds for
+// 192 -> 384 and the merged ConvTranspose 384 -> 96, 4.5 for 384 -> 192).  The regions of that last partial round run as a SECOND
+// launch with one 32-channel tile per workgroup (NT = 1): three times the blocks at ~0.42 of the time each, i.e. the tail costs
+// 0.42 (or 0.84) of a round instead of one.  Returns the number of regions of the main launch (a multiple of 8; == nregions: no split).
+// fp32 form only: the bf16 x 3 weights are laid out per NT.
+static int wino32_tail_split(int nregions, int group_blocks /* blocks per 8 regions */, int NT) {
+    static int ncu = -1;
+    if (ncu < 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+        const char* e = getenv("ADH_WINO32_TAIL");      // A/B switch: 0 = one launch per layer
+        if (e && atoi(e) == 0) ncu = 0;
+    }
+    if (ncu <= 0 || NT < 2) return nregions;
+    const int ngroups = (nregions + 7) / 8, nblocks = ngroups * group_blocks;
+    const int full = nblocks / ncu * ncu;                        // blocks of the full rounds
+    if (full == 0 || full == nblocks) return nregions;
+    const int main_groups = full / group_blocks;                 // (whole groups of 8 regions only)
+    const int tail_blocks = nblocks - main_groups * group_blocks;
+    const int tail_rounds = (NT * tail_blocks + ncu - 1) / ncu;  // rounds of the NT = 1 tail launch
+    const double cost = tail_rounds * (NT == 3 ? 0.42 : 0.56), now = (double)((tail_blocks + ncu - 1) / ncu);
+    if (main_groups == 0 || cost > 0.6 * now) return nregions;   // (0.84 of a round for a tail of more than a third: measured slower)
+    return main_groups * 8;
+}
+
 template <int NT, bool BF3 = false>
-static int launch_wino32(hipStream_t s, const adh_conv_desc* d, Wino32Geom g) {
+static int launch_wino32_part(hipStream_t s, const adh_conv_desc* d, Wino32Geom g, int region0, int region_end) {
     g.ncog = d->NcP / (32 * NT);
-    const int nblocks = ((g.nregions + 7) / 8) * g.ncog * 8;
+    g.region0 = region0;
+    g.nregions = region_end;
+    const int nblocks = ((region_end - region0 + 7) / 8) * g.ncog * 8;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<NT, BF3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((conv_wino32_kernel<NT, BF3>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, *d, g);
     return adh_check_launch();
+}
+template <int NT, bool BF3 = false>
+static int launch_wino32(hipStream_t s, const adh_conv_desc* d, Wino32Geom g) {
+    const int nreg = g.nregions;
+    const int main_regions = BF3 ? nreg : wino32_tail_split(nreg, 8 * (d->NcP / (32 * NT)), NT);
+    const int rc = launch_wino32_part<NT, BF3>(s, d, g, 0, main_regions);
+    if (rc || main_regions == nreg) return rc;
+    return launch_wino32_part<1, BF3>(s, d, g, main_regions, nreg);
 }
 
 static int wino32_forward_impl(void* stream, const adh_conv_desc* d, bool bf3) {
@@ -1245,35 +1284,39 @@ static int wino32_forward_multi_impl(void* stream, const adh_conv_desc* descs, i
     }
     const int nt = descs[0].NcP / 32;
     const int NT = nt % 3 == 0 ? 3 : (nt % 2 == 0 ? 2 : 1);
-    g0.ncog = descs[0].NcP / (32 * NT);
-    g0.nmerge = n;
-    g0.mblocks = ((g0.nregions + 7) / 8) * g0.ncog * 8;
-    const int nblocks = n * g0.mblocks;
     hipStream_t s = (hipStream_t)stream;
-    if (bf3) {
-        if (NT == 3) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL((conv_wino32_kernel<3, true>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
-        } else if (NT == 2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL((conv_wino32_kernel<2, true>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
+    const int nreg = g0.nregions;
+    // (the regions of the last partial round as a second launch of NT = 1 workgroups: wino32_tail_split)
+    const int main_regions = bf3 ? nreg : wino32_tail_split(nreg, 8 * n * (descs[0].NcP / (32 * NT)), NT);
+    for (int part = 0; part < 2; ++part) {
+        const int r0 = part ? main_regions : 0, r1 = part ? nreg : main_regions, nt_part = part ? 1 : NT;
+        if (r1 <= r0) break;
+        g0.ncog = descs[0].NcP / (32 * nt_part);
+        g0.nmerge = n;
+        g0.region0 = r0;
+        g0.nregions = r1;
+        g0.mblocks = ((r1 - r0 + 7) / 8) * g0.ncog * 8;
+        const int nblocks = n * g0.mblocks;
+#define W3_LAUNCH_MULTI(NT_, BF_)                                                                                                       \
+        do {                                                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<NT_, BF_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                                       \
+            hipLaunchKernelGGL((conv_wino32_kernel<NT_, BF_>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);                 \
+        } while (0)
+        if (bf3) {
+            if (nt_part == 3) W3_LAUNCH_MULTI(3, true);
+            else if (nt_part == 2) W3_LAUNCH_MULTI(2, true);
+            else W3_LAUNCH_MULTI(1, true);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL((conv_wino32_kernel<1, true>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
+            if (nt_part == 3) W3_LAUNCH_MULTI(3, false);
+            else if (nt_part == 2) W3_LAUNCH_MULTI(2, false);
+            else W3_LAUNCH_MULTI(1, false);
         }
-        return adh_check_launch();
+#undef W3_LAUNCH_MULTI
+        const int rc = adh_check_launch();
+        if (rc) return rc;
     }
-    if (NT == 3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((conv_wino32_kernel<3>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
-    } else if (NT == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((conv_wino32_kernel<2>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((conv_wino32_kernel<1>), dim3(nblocks), dim3(256), W3_LDS_BYTES, s, descs[0], g0);
-    }
-    return adh_check_launch();
+    return ADH_OK;
 }
 
 extern "C" int adh_conv_wino32_forward_multi(void* stream, const adh_conv_desc* descs, int n) {
