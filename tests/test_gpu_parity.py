@@ -405,7 +405,10 @@ def test_medium_and_light_fullwidth_vs_oracle_seeded(tag, algo, monkeypatch):
 
 @pytest.mark.parametrize("N,Ci,Co,Hh,Ww", [(2, 16, 16, 15, 23), (2, 32, 32, 7, 11), (1, 16, 48, 15, 23), (2, 96, 96, 16, 64),
                                            (1, 64, 192, 24, 40), (3, 32, 16, 8, 96), (1, 16, 16, 41, 66),
-                                           (1, 32, 64, 24, 96), (1, 96, 96, 40, 160), (1, 48, 32, 40, 128)])   # interior regions
+                                           (1, 32, 64, 24, 96), (1, 96, 96, 40, 160), (1, 48, 32, 40, 128),    # interior regions
+                                           # more regions than CUs, ragged in both directions: the persistent form of conv_wino43_kernel
+                                           # (a workgroup walks several regions; border -> interior -> border slot tables)
+                                           (3, 32, 64, 250, 500), (2, 16, 96, 135, 1000)])
 @pytest.mark.parametrize("algo", ["f23", "f43", "f43-bf16x3"])
 def test_winograd_matches_direct_path(N, Ci, Co, Hh, Ww, algo, monkeypatch):
     """Same layer through conv_wino_kernel (F(2x2,3x3)) / conv_wino43_kernel (F(4x4,3x3)) and the direct kernel: outputs
@@ -684,7 +687,10 @@ def test_stem_weight_gradient(N, Co, Hh, Ww, monkeypatch):
 
 
 @pytest.mark.parametrize("kind,N,Ci,Co,Hh,Ww", [("conv", 1, 32, 96, 48, 96), ("conv", 2, 16, 64, 26, 50), ("conv", 1, 96, 192, 24, 192),
-                                                ("convT", 1, 64, 96, 12, 48), ("convT", 2, 32, 32, 13, 25), ("convT", 1, 16, 192, 24, 96)])
+                                                ("convT", 1, 64, 96, 12, 48), ("convT", 2, 32, 32, 13, 25), ("convT", 1, 16, 192, 24, 96),
+                                                # a last partial round of less than a third of 256 CUs: the regions of that round run as a
+                                                # second launch of NT = 1 workgroups (wino32_tail_split): 336 blocks / 320 merged
+                                                ("conv", 3, 32, 96, 250, 940), ("convT", 1, 32, 96, 66, 600)])
 @pytest.mark.parametrize("contract", ["fp32", "bf16x3"])
 def test_winograd32_matches_direct_path(kind, N, Ci, Co, Hh, Ww, contract, monkeypatch):
     """k4 s2 convolution / transposed convolution and their data gradients through conv_wino32_kernel (F(3x3,2x2), one or
@@ -728,7 +734,8 @@ def test_winograd32_matches_direct_path(kind, N, Ci, Co, Hh, Ww, contract, monke
 # BatchNorm-backward sums in the consumer's data-gradient epilogue (adh_conv_wino43_dgrad_bnred)
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,Cp,Cn,Hh,Ww", [(2, 96, 96, 40, 72), (1, 64, 32, 33, 47), (2, 48, 16, 16, 32), (1, 16, 16, 24, 40),
-                                           (1, 192, 192, 16, 64)])
+                                           (1, 192, 192, 16, 64),
+                                           (2, 32, 32, 250, 500)])    # 512 ragged regions on 256 CUs: the persistent form
 def test_fused_bn_backward_sums_match_the_reduce_pass(N, Cp, Cn, Hh, Ww):
     """Producer: Conv(.. -> Cp) + train BN + ReLU; consumer: Conv3x3(Cp -> Cn).  The consumer's data-gradient launch with the
     producer's sums in its epilogue must (a) write the same gradient, bit for bit, as the plain launch, and (b) give the
