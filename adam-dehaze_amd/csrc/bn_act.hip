@@ -236,10 +236,18 @@ extern "C" int adh_bn_eval_bwd_vectors(void* stream, int C, int C4, const float*
 #ifndef EW_UNROLL
 #define EW_UNROLL 8
 #endif
-#ifndef EW_MAXBLK
-#define EW_MAXBLK (256 * 8)
+// Grid caps (blocks of 256 threads; a block walks EW_UNROLL pixels per loop trip at a stride of the whole grid).  Swept on
+// 8 x 512 x 1024 x 96 at the end of round 4 (profiles/r04b_sweep_bn_grid.txt; caps of 8 / 32 / 64 / 128 / 512 x 256 blocks): the
+// two-stream kernel (bn_apply: y -> out) is fastest with one trip per thread (0.608 -> 0.541 ms), the three-stream one
+// (bn_bwd_apply: g, y -> g_y) at 32 x 256 (1.220 -> 1.135 ms) and gets slower again beyond -- the optimum is not monotonic in
+// the grid size (which pages of which HBM channels the concurrent blocks touch), so these are measured constants, not a rule.
+#ifndef EW_MAXBLK_APPLY
+#define EW_MAXBLK_APPLY (256 * 512)
 #endif
-static int ew_blocks(int64_t P, int CQ) {
+#ifndef EW_MAXBLK_BWD
+#define EW_MAXBLK_BWD (256 * 32)
+#endif
+static int ew_blocks(int64_t P, int CQ, int EW_MAXBLK) {
     int g = CQ, r = 256;   // gcd(CQ, 256)
     while (r) { const int t = g % r; g = r; r = t; }
     const int mult = CQ / g;                                  // blocks must be a multiple of this
@@ -300,7 +308,7 @@ extern "C" int adh_bn_apply(void* stream, const float* y, int y_cs, const float*
         return ADH_E_ARG;
     const int CQ = C / 4;
     if (mask_bits && ((CQ & 1) || act != ADH_ACT_RELU)) return ADH_E_ARG;   // nibble pairs: an even number of quads per pixel
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(P, CQ)), dim3(256), 0, (hipStream_t)stream, y, y_cs, scale, shift,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(P, CQ, EW_MAXBLK_APPLY)), dim3(256), 0, (hipStream_t)stream, y, y_cs, scale, shift,
                        residual, res_cs, act, out, out_cs, P, CQ, mask_bits);
     return adh_check_launch();
 }
@@ -542,7 +550,7 @@ extern "C" int adh_bn_bwd_apply(void* stream, const float* g_out, int g_cs, cons
     if (mask_ss && !(training && act == ADH_ACT_RELU)) return ADH_E_ARG;
     if (act == ADH_ACT_RELU && !out && !mask_ss && !mask_bits) return ADH_E_ARG;
     if (mask_bits && (((C / 4) & 1) || act != ADH_ACT_RELU)) return ADH_E_ARG;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P, C / 4)), dim3(256), 0, (hipStream_t)stream, g_out, g_cs, out, out_cs, act,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P, C / 4, EW_MAXBLK_BWD)), dim3(256), 0, (hipStream_t)stream, g_out, g_cs, out, out_cs, act,
                        y, y_cs, mean, invstd, coef, training, g_y, gy_cs, g_res, gres_cs, P, C, mask_ss, mask_bits);
     return adh_check_launch();
 }
