@@ -8,7 +8,17 @@
 // torch.max / adaptive_max_pool2d on CPU (ReLU outputs contain exact zeros, so ties do occur).
 #include "common.h"
 
+#ifndef POOL_PPB
 #define POOL_PPB 1024
+#endif
+#ifndef CBAM_SCALE_MAXBLK
+#define CBAM_SCALE_MAXBLK 65536    // blocks per image of the two-stream kernels (cbam_scale_kernel, cbam_bwd_e_kernel): one trip per thread
+                                   // (swept at the end of round 4, profiles/r04b_sweep_cbam_grid.txt: cbam_apply 1.78 -> 1.69 ms per step, cbam_bwd_e 1.57 -> 1.52
+                                   // against the cap of 1024; POOL_PPB = 256 would take 0.2 ms off cbam_bwd_c and add 0.05 to cbam_pool: shared block count, left)
+#endif
+#ifndef CBAM_ROW_MAXBLK
+#define CBAM_ROW_MAXBLK 2048       // blocks per image of the per-pixel kernels (cbam_spatial_stats_kernel, cbam_bwd_a_kernel)
+#endif
 
 extern "C" int adh_cbam_pool_num_blocks(int HW) { return adh_ceil_div(HW, POOL_PPB); }
 
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const float* __
 extern "C" int adh_cbam_spatial_stats(void* stream, const float* x, int x_cs, const float* ca, int N, int HW, int C,
                                       float* smap, int32_t* cidx) {
     if (!x || !ca || !smap || !cidx || N < 1 || HW < 1 || C < 4 || (C & 3)) return ADH_E_ARG;
-    const int blocks = adh_min_i(adh_ceil_div(HW, 32), 2048);
+    const int blocks = adh_min_i(adh_ceil_div(HW, 32), CBAM_ROW_MAXBLK);
     hipLaunchKernelGGL(cbam_spatial_stats_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, x, x_cs, ca, HW, C,
                        smap, cidx);
     return adh_check_launch();
@@ -313,7 +323,7 @@ static int cbam_scale_blocks(int64_t HW, int CQ) {
     while (r) { const int t = g % r; g = r; r = t; }
     const int mult = CQ / g;
     int64_t want = (HW * CQ + 256 * 8 - 1) / (256 * 8);
-    if (want > 1024) want = 1024;
+    if (want > CBAM_SCALE_MAXBLK) want = CBAM_SCALE_MAXBLK;
     int64_t blocks = (want + mult - 1) / mult * mult;
     if (blocks < mult) blocks = mult;
     return (int)blocks;
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(256) void cbam_bwd_a_kernel(const float* __restrict
 extern "C" int adh_cbam_bwd_a(void* stream, const float* g, int g_cs, const float* x, int x_cs, const float* ca,
                               const float* sa, int N, int HW, int C, float* gsa_pre) {
     if (!g || !x || !ca || !sa || !gsa_pre || N < 1 || HW < 1 || C < 4 || (C & 3)) return ADH_E_ARG;
-    const int blocks = adh_min_i(adh_ceil_div(HW, 32), 2048);
+    const int blocks = adh_min_i(adh_ceil_div(HW, 32), CBAM_ROW_MAXBLK);
     hipLaunchKernelGGL(cbam_bwd_a_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, g, g_cs, x, x_cs, ca, sa, HW,
                        C, gsa_pre);
     return adh_check_launch();
