@@ -317,7 +317,8 @@ extern "C" int adh_bn_apply(void* stream, const float* y, int y_cs, const float*
 // backward pass 1: per-block sums of g and g*xhat
 // ---------------------------------------------------------------------------------------------
 #ifndef BNB_PPB
-#define BNB_PPB 2048  // pixels per block
+#define BNB_PPB 512   // pixels per block (swept at the end of round 4 over 256 .. 8192, profiles/r04b_sweep_bn_grid.txt: 2048 left the half- and
+                      // quarter-resolution layers with 512 / 128 blocks on 256 CUs; bn_bwd_reduce 5.36 -> 4.65 ms per step)
 #endif
 #ifndef BNB_UNROLL
 #define BNB_UNROLL 4  // pixels per trip and thread (x 2 streams of 16-byte loads in flight)

@@ -9,12 +9,12 @@
 #include "common.h"
 
 #ifndef POOL_PPB
-#define POOL_PPB 1024
+#define POOL_PPB 512      // pixels per block of cbam_pool_partial_kernel and cbam_bwd_c_kernel (1024 before: cbam_bwd_c 1.61 -> 1.41 ms per step, cbam_pool 0.85 -> 0.80)
 #endif
 #ifndef CBAM_SCALE_MAXBLK
 #define CBAM_SCALE_MAXBLK 65536    // blocks per image of the two-stream kernels (cbam_scale_kernel, cbam_bwd_e_kernel): one trip per thread
                                    // (swept at the end of round 4, profiles/r04b_sweep_cbam_grid.txt: cbam_apply 1.78 -> 1.69 ms per step, cbam_bwd_e 1.57 -> 1.52
-                                   // against the cap of 1024; POOL_PPB = 256 would take 0.2 ms off cbam_bwd_c and add 0.05 to cbam_pool: shared block count, left)
+                                   // against the cap of 1024)
 #endif
 #ifndef CBAM_ROW_MAXBLK
 #define CBAM_ROW_MAXBLK 2048       // blocks per image of the per-pixel kernels (cbam_spatial_stats_kernel, cbam_bwd_a_kernel)
