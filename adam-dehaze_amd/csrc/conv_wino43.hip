@@ -11,13 +11,16 @@
 // the textbook points and 1.0e-6..1.5e-6 for the direct algorithm (point choice after Barabasz et al., "Error analysis
 // and improving the accuracy of Winograd convolution for deep neural networks", 2018).  fp32 arithmetic throughout.
 //
-// Workgroup = 4 waves x 512 registers: output region 16 rows x 32 cols = 4 x 8 tiles of 4x4 = one 32-tile
-// MFMA row block, x 32*NT output channels; the 36 frequencies are dealt 9 per wave: 9*NT accumulator tiles, the first
+// Workgroup = 4 waves x 512 registers, PERSISTENT since round 4: one per CU, walking virtual blocks
+// v = blockIdx.x + k gridDim.x = (output-channel group, region); output region 16 rows x 32 cols = 4 x 8 tiles of 4x4 = one
+// 32-tile MFMA row block, x 32*NT output channels; the 36 frequencies are dealt 9 per wave: 9*NT accumulator tiles, the first
 // 16 pinned to AGPRs.  Per chunk of 16 input channels:
 //   * the 18 x 34 raw halo arrives by LDS-DMA in the layout [row][column mod 4][index][16 ch] (34 pixel slots per row)
 //     so that the patch columns of adjacent tiles are adjacent in LDS; every lane's source offset comes from a 612-entry
-//     table built once per workgroup (clamped coordinates: all lanes always load, out-of-image cells are zeroed after
-//     landing); 40 pieces per chunk, 10 per wave, double buffered;
+//     slot table (one region-independent table of offsets relative to the halo's first pixel; border regions get an absolute
+//     one): all lanes always load, a slot outside the image has an OUT-OF-RANGE offset, for which the LDS-DMA unit writes zeros
+//     (tools/micro/dma_oob.hip) -- the padding costs no pass over the landed halo; 40 pieces per chunk, 10 per wave, staged
+//     during the previous chunk's contraction -- the last chunk of a region stages the first chunk of the workgroup's NEXT region;
 //   * the input transform runs as two 1-D passes through LDS (column pass raw -> T, row pass T -> V in place): ~12
 //     registers live instead of the 72 a 6x6 tile would need next to 27 accumulator tiles;
 //   * contraction: per wave 18 groups (9 frequencies x two 8-channel halves) of 4*NT MFMAs; A = one ds_read_b128 of
@@ -28,7 +31,8 @@
 // V and raw double-buffered at eight channels, was parity-green and exactly as fast; every v_pk_fma_f32 of the transform takes
 // ~16 cycles of the fp32 FMA datapath the MFMA runs on wherever it is issued.  profiles/r04_ab_wino43_pipelined_transform.txt,
 // commit 32ab26b).
-// Epilogue: accumulators -> LDS M[36][32 tiles][32 co] one channel tile at a time, A^T M A and the fused epilogue.
+// Epilogue: six rounds of (32-channel tile, half region): accumulators -> LDS M[36][16 tiles][32 co] -- exactly V's 72 KB, so the
+// staged halo of the next region survives --, A^T M A and the fused epilogue, the next round's M write dealt over the row pass.
 #include "common.h"
 #ifndef W_STORE_AUX
 #define W_STORE_AUX 0   // cache policy of the epilogue stores (buffer instruction aux bits; 2 = nt)
