@@ -47,7 +47,9 @@
 #define W4_STORE_NOPS 1   // wait states - 1 after each epilogue store (see the comment at the store)
 #endif
 #define W4_KC 16
-#define W4_ZERO_C false   // (see the zeroing of the accumulators at the top of a region)
+#define W4_ZERO_C false   // the FIRST / Z template parameters below (first MFMA on a tile with C = 0 instead of zeroed accumulators) are the
+                          // switch of a measured experiment: they need the contraction instantiated twice behind `if (c == 0)`, and hipcc then
+                          // spills ~700 registers; the product zeroes the accumulators with MFMAs at the top of a region
 #define W4_TILES 32
 #define W4_VF (36 * W4_TILES * W4_KC)              // floats of V (73,728 B)
 #define W4_SLOTS 612                               // pixel slots of the raw halo: 18 rows x 34 columns
